@@ -1,0 +1,344 @@
+"""CPU restatement of the reference's Hu / PCA feature arithmetic (NumPy).
+
+TEST INFRASTRUCTURE ONLY: this module is the checker.  Only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` import
+it; the product package never does.
+
+* ``compute_pca_features`` follows reference
+  ``src/features/extract_3d_pca_features.py:59-145`` step for step with the same
+  NumPy/LAPACK calls (``np.cov`` ddof=1, ``np.linalg.eigh``, ``np.linspace``,
+  ``np.histogram``), so on the same input it returns the same float32 vector as
+  the reference; ``tests/golden/pca_golden.npz`` (made by importing the
+  reference, see ``tests/golden/make_golden.py``) pins that.
+* ``moments_u8`` / ``hu_from_moments`` / ``hu_log`` restate
+  ``extract_2d_hu.py:443-478``; the arithmetic inside ``cv2.moments`` /
+  ``cv2.HuMoments`` is OpenCV's (absent from this image, unpinned version) and
+  is restated from its published algorithm.  PARITY PIN for Hu: committed
+  silhouette panels + feature table only; per-view last digits against a given
+  OpenCV build are "parity unpinned".
+* ``hu_groupstat`` restates ``extract_2d_hu.py:641-644`` (float32 mean/std).
+* ``contour_points`` defines the build's 2-D contour point set (no reference
+  counterpart); the descriptor of it is ``compute_pca_features`` on (x, y, 0).
+* ``libfx_oracle.so`` (``oracle/fx_oracle.c``) holds the same Hu path in C for
+  speed; ``load_c_oracle`` binds it.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+
+MOMENT_KEYS = (
+    "m00", "m10", "m01", "m20", "m11", "m02", "m30", "m21", "m12", "m03",
+    "mu20", "mu11", "mu02", "mu30", "mu21", "mu12", "mu03",
+    "nu20", "nu11", "nu02", "nu30", "nu21", "nu12", "nu03",
+)
+
+
+# --------------------------------------------------------------------------
+# Hu path
+# --------------------------------------------------------------------------
+def binarise(img: np.ndarray, thresh: int, on_value: int = 255) -> np.ndarray:
+    """``(img > thresh) * on_value`` as uint8; ``thresh < 0`` returns img
+    unchanged (reference extract_2d_hu.py:163,258)."""
+    img = np.asarray(img, dtype=np.uint8)
+    if thresh < 0:
+        return img
+    return ((img > thresh).astype(np.uint8) * np.uint8(on_value)).astype(np.uint8)
+
+
+def raw_moments_exact(img: np.ndarray) -> list[int]:
+    """The ten raw moments m_pq = sum x^p y^q I(x, y) as exact Python ints
+    (x = column, y = row, origin at the top-left pixel)."""
+    a = np.asarray(img, dtype=np.uint8).astype(object)
+    h, w = a.shape
+    x = np.arange(w, dtype=object)
+    y = np.arange(h, dtype=object)
+    r0 = a.sum(axis=1)
+    r1 = (a * x).sum(axis=1)
+    r2 = (a * x * x).sum(axis=1)
+    r3 = (a * x * x * x).sum(axis=1)
+    return [
+        int(r0.sum()), int(r1.sum()), int((y * r0).sum()),
+        int(r2.sum()), int((y * r1).sum()), int((y * y * r0).sum()),
+        int(r3.sum()), int((y * r2).sum()), int((y * y * r1).sum()),
+        int((y * y * y * r0).sum()),
+    ]
+
+
+def complete_moments(raw10) -> np.ndarray:
+    """OpenCV completeMomentState in IEEE double, operation order kept."""
+    m = np.zeros(24, dtype=np.float64)
+    m[:10] = [float(v) for v in raw10]
+    m00, m10, m01, m20, m11, m02, m30, m21, m12, m03 = (np.float64(v) for v in m[:10])
+    cx = cy = inv = np.float64(0.0)
+    if abs(m00) > np.finfo(np.float64).eps:
+        inv = np.float64(1.0) / m00
+        cx = m10 * inv
+        cy = m01 * inv
+    mu20 = m20 - m10 * cx
+    mu11 = m11 - m10 * cy
+    mu02 = m02 - m01 * cy
+    m[10], m[11], m[12] = mu20, mu11, mu02
+    m[13] = m30 - cx * (3 * mu20 + cx * m10)
+    mu11 = mu11 + mu11
+    m[14] = m21 - cx * (mu11 + cx * m01) - cy * mu20
+    m[15] = m12 - cy * (mu11 + cy * m10) - cx * mu02
+    m[16] = m03 - cy * (3 * mu02 + cy * m01)
+    s = np.sqrt(abs(inv))
+    s2 = inv * inv
+    s3 = s2 * s
+    m[17:20] = m[10:13] * s2
+    m[20:24] = m[13:17] * s3
+    return m
+
+
+def moments_u8(img: np.ndarray, thresh: int = -1, on_value: int = 255) -> np.ndarray:
+    """cv2.moments of a uint8 image as a 24-vector ordered like MOMENT_KEYS."""
+    return complete_moments(raw_moments_exact(binarise(img, thresh, on_value)))
+
+
+def hu_from_moments(m: np.ndarray) -> np.ndarray:
+    """cv2.HuMoments, operation order kept."""
+    nu20, nu11, nu02, nu30, nu21, nu12, nu03 = (np.float64(v) for v in m[17:24])
+    t0 = nu30 + nu12
+    t1 = nu21 + nu03
+    q0, q1 = t0 * t0, t1 * t1
+    n4 = 4 * nu11
+    s = nu20 + nu02
+    d = nu20 - nu02
+    hu = np.zeros(7, dtype=np.float64)
+    hu[0] = s
+    hu[1] = d * d + n4 * nu11
+    hu[3] = q0 + q1
+    hu[5] = d * (q0 - q1) + n4 * t0 * t1
+    t0 = t0 * (q0 - 3 * q1)
+    t1 = t1 * (3 * q0 - q1)
+    q0 = nu30 - 3 * nu12
+    q1 = 3 * nu21 - nu03
+    hu[2] = q0 * q0 + q1 * q1
+    hu[4] = q0 * t0 + q1 * t1
+    hu[6] = q1 * t0 - q0 * t1
+    return hu
+
+
+def hu_log(hu: np.ndarray) -> np.ndarray:
+    """-sign(h) * log10(|h| + 1e-300) in float64; inf/nan -> 0
+    (extract_2d_hu.py:471-478, before the float32 cast)."""
+    out = np.zeros(7, dtype=np.float64)
+    for i, h in enumerate(np.asarray(hu, dtype=np.float64)):
+        v = -np.sign(h) * np.log10(abs(float(h)) + 1e-300)
+        if np.isinf(v) or np.isnan(v):
+            v = 0.0
+        out[i] = v + 0.0
+    return out
+
+
+def compute_hu_from_image(img: np.ndarray, thresh: int = -1, on_value: int = 255) -> np.ndarray:
+    """float32[7] log-Hu vector of a uint8 image (extract_2d_hu.py:443-478)."""
+    return hu_log(hu_from_moments(moments_u8(img, thresh, on_value))).astype(np.float32)
+
+
+def hu_textbook(img: np.ndarray) -> np.ndarray:
+    """Hu invariants from the definition: central moments summed directly as
+    sum (x-xc)^p (y-yc)^q I in float64, eta = mu / m00^(1+(p+q)/2), then the
+    seven classical polynomials.  Independent of OpenCV's evaluation order."""
+    a = np.asarray(img, dtype=np.float64)
+    h, w = a.shape
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    m00 = a.sum()
+    if m00 == 0:
+        return np.zeros(7)
+    xc, yc = (xx * a).sum() / m00, (yy * a).sum() / m00
+    dx, dy = xx - xc, yy - yc
+
+    def eta(p, q):
+        return ((dx ** p) * (dy ** q) * a).sum() / m00 ** (1 + (p + q) / 2.0)
+
+    n20, n11, n02 = eta(2, 0), eta(1, 1), eta(0, 2)
+    n30, n21, n12, n03 = eta(3, 0), eta(2, 1), eta(1, 2), eta(0, 3)
+    a0, a1 = n30 + n12, n21 + n03
+    b0, b1 = n30 - 3 * n12, 3 * n21 - n03
+    return np.array([
+        n20 + n02,
+        (n20 - n02) ** 2 + 4 * n11 ** 2,
+        b0 ** 2 + b1 ** 2,
+        a0 ** 2 + a1 ** 2,
+        b0 * a0 * (a0 ** 2 - 3 * a1 ** 2) + b1 * a1 * (3 * a0 ** 2 - a1 ** 2),
+        (n20 - n02) * (a0 ** 2 - a1 ** 2) + 4 * n11 * a0 * a1,
+        b1 * a0 * (a0 ** 2 - 3 * a1 ** 2) - b0 * a1 * (3 * a0 ** 2 - a1 ** 2),
+    ])
+
+
+def hu_groupstat(hulog7: np.ndarray, offsets=None) -> np.ndarray:
+    """mean || std(ddof=0) per group of view rows in float32
+    (extract_2d_hu.py:641-644).  offsets=None treats all rows as one group."""
+    rows = np.asarray(hulog7, dtype=np.float32)
+    if offsets is None:
+        offsets = [0, rows.shape[0]]
+    out = np.zeros((len(offsets) - 1, 14), dtype=np.float32)
+    for g in range(len(offsets) - 1):
+        arr = rows[offsets[g]:offsets[g + 1]]
+        with np.errstate(all="ignore"):
+            out[g, :7] = np.mean(arr, axis=0).astype(np.float32)
+            out[g, 7:] = np.std(arr, axis=0, ddof=0).astype(np.float32)
+    return out
+
+
+# --------------------------------------------------------------------------
+# PCA path
+# --------------------------------------------------------------------------
+def compute_pca_features(points: np.ndarray, n_bins: int = 8, normalize: bool = False,
+                         return_eig: bool = False):
+    """float32[9 + n_bins] descriptor of an N x 3 float64 point set
+    (extract_3d_pca_features.py:59-145).  With return_eig also returns the
+    float64 (lambda1..3, v1) used, for eigenvalue / eigenvector tolerances."""
+    pts = np.asarray(points)
+    if pts.shape[0] < 3:
+        raise ValueError("too few points (<3)")
+    centred = pts - pts.mean(axis=0)
+    if normalize:
+        radius = np.linalg.norm(centred, axis=1)
+        rmax = float(np.max(radius)) if radius.size > 0 else 0.0
+        if rmax > 0:
+            centred = centred / rmax
+    cov = np.cov(centred, rowvar=False, bias=False)
+    cov = (cov + cov.T) / 2.0
+    w, v = np.linalg.eigh(cov)
+    w, v = w[::-1], v[:, ::-1]
+    w = np.where(w < 0.0, np.clip(w, a_min=0.0, a_max=None), w).astype(float)
+    l1, l2, l3 = float(w[0]), float(w[1]), float(w[2])
+    trace = l1 + l2 + l3
+    denom = trace if trace > 1e-12 else 1e-12
+    head = [l1, l2, l3, l1 / denom, l2 / denom, l3 / denom,
+            l1 / (l2 + 1e-12), l2 / (l3 + 1e-12), trace]
+    axis1 = v[:, 0].astype(np.float64)
+    proj = np.abs(centred.dot(axis1))
+    top = float(np.max(proj)) if proj.size > 0 else 0.0
+    if top <= 0:
+        hist = np.zeros(n_bins, dtype=float)
+        hist[0] = 1.0
+    else:
+        edges = np.linspace(0.0, top, n_bins + 1, endpoint=True)
+        hist, _ = np.histogram(proj, bins=edges)
+        hist = hist.astype(float)
+        tot = hist.sum()
+        hist = hist / tot if tot > 0 else np.zeros_like(hist, dtype=float)
+    vec = np.asarray(head + [float(c) for c in hist.tolist()], dtype=np.float32)
+    if return_eig:
+        return vec, np.array([l1, l2, l3, axis1[0], axis1[1], axis1[2]], dtype=np.float64)
+    return vec
+
+
+def contour_points(img: np.ndarray, thresh: int = 127) -> np.ndarray:
+    """Foreground pixels (v > thresh; 127 when thresh < 0) with a 4-neighbour
+    that is background or outside the image, as float64 rows (x, y, 0) in
+    row-major pixel order."""
+    t = 127 if thresh < 0 else thresh
+    fg = np.asarray(img, dtype=np.uint8) > t
+    pad = np.pad(fg, 1, mode="constant", constant_values=False)
+    interior = pad[:-2, 1:-1] & pad[2:, 1:-1] & pad[1:-1, :-2] & pad[1:-1, 2:]
+    ys, xs = np.nonzero(fg & ~interior)
+    out = np.zeros((ys.size, 3), dtype=np.float64)
+    out[:, 0] = xs
+    out[:, 1] = ys
+    return out
+
+
+def contour_pca_features(img: np.ndarray, thresh: int = 127, n_bins: int = 8,
+                         return_eig: bool = False):
+    """PCA descriptor of the contour point set; NaN vector when it has < 3
+    points (the reference function raises ValueError there)."""
+    pts = contour_points(img, thresh)
+    if pts.shape[0] < 3:
+        vec = np.full(9 + n_bins, np.nan, dtype=np.float32)
+        return (vec, np.full(6, np.nan)) if return_eig else vec
+    return compute_pca_features(pts, n_bins=n_bins, normalize=False, return_eig=return_eig)
+
+
+# --------------------------------------------------------------------------
+# C oracle binding
+# --------------------------------------------------------------------------
+def build_c_oracle(force: bool = False) -> Path:
+    so = _HERE / "libfx_oracle.so"
+    src = _HERE / "fx_oracle.c"
+    if force or not so.exists() or (src.exists() and so.stat().st_mtime < src.stat().st_mtime):
+        subprocess.run(["make", "-C", str(_HERE), "-B" if force else "-s", "libfx_oracle.so"],
+                       check=True, stdout=subprocess.DEVNULL)
+    return so
+
+
+class COracle:
+    """ctypes view of libfx_oracle.so."""
+
+    def __init__(self, path: os.PathLike | None = None):
+        self.lib = ctypes.CDLL(str(path or build_c_oracle()))
+        c_u8p = ctypes.POINTER(ctypes.c_uint8)
+        c_dp = ctypes.POINTER(ctypes.c_double)
+        c_fp = ctypes.POINTER(ctypes.c_float)
+        c_i64p = ctypes.POINTER(ctypes.c_int64)
+        self.lib.fxo_hu_batch_u8.argtypes = [
+            c_u8p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+            ctypes.c_int, ctypes.c_int, ctypes.c_int, c_dp, c_dp, c_dp, c_fp]
+        self.lib.fxo_hu_batch_u8.restype = None
+        self.lib.fxo_hu_groupstat.argtypes = [c_fp, c_i64p, ctypes.c_int64, c_fp]
+        self.lib.fxo_hu_groupstat.restype = None
+        self.lib.fxo_contour_points_u8.argtypes = [
+            c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
+            ctypes.POINTER(ctypes.c_int32), ctypes.c_int64]
+        self.lib.fxo_contour_points_u8.restype = ctypes.c_int64
+
+    def hu_batch(self, imgs: np.ndarray, thresh: int = -1, on_value: int = 255, exact: bool = False):
+        """imgs: uint8 [B, H, W] C-contiguous.  Returns dict of moments24 [B,24] f64,
+        hu7 [B,7] f64, hulog7_f64 [B,7] f64, hulog7 [B,7] f32."""
+        imgs = np.ascontiguousarray(imgs, dtype=np.uint8)
+        if imgs.ndim == 2:
+            imgs = imgs[None]
+        b, h, w = imgs.shape
+        m = np.zeros((b, 24), dtype=np.float64)
+        hu = np.zeros((b, 7), dtype=np.float64)
+        lg = np.zeros((b, 7), dtype=np.float64)
+        lf = np.zeros((b, 7), dtype=np.float32)
+        as_p = lambda a, t: a.ctypes.data_as(ctypes.POINTER(t))
+        self.lib.fxo_hu_batch_u8(as_p(imgs, ctypes.c_uint8), b, h, w, w, h * w, int(thresh),
+                                 int(on_value), int(bool(exact)), as_p(m, ctypes.c_double),
+                                 as_p(hu, ctypes.c_double), as_p(lg, ctypes.c_double),
+                                 as_p(lf, ctypes.c_float))
+        return {"moments24": m, "hu7": hu, "hulog7_f64": lg, "hulog7": lf}
+
+    def hu_groupstat(self, hulog7: np.ndarray, offsets) -> np.ndarray:
+        rows = np.ascontiguousarray(hulog7, dtype=np.float32)
+        off = np.ascontiguousarray(offsets, dtype=np.int64)
+        out = np.zeros((off.size - 1, 14), dtype=np.float32)
+        self.lib.fxo_hu_groupstat(rows.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                  off.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+                                  off.size - 1,
+                                  out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+        return out
+
+    def contour_points(self, img: np.ndarray, thresh: int = 127) -> np.ndarray:
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape
+        cap = h * w
+        xy = np.zeros((cap, 2), dtype=np.int32)
+        n = self.lib.fxo_contour_points_u8(img.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
+                                           h, w, w, int(thresh),
+                                           xy.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), cap)
+        out = np.zeros((n, 3), dtype=np.float64)
+        out[:, :2] = xy[:n]
+        return out
+
+
+_C = None
+
+
+def load_c_oracle() -> COracle:
+    global _C
+    if _C is None:
+        _C = COracle()
+    return _C

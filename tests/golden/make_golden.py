@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""Regenerates the golden fixtures in this directory.  Runs only where the
+reference checkout is mounted (default /root/reference); the fixtures it writes
+are committed so that no test needs the reference at run time.
+
+pca_golden.npz
+    Inputs and outputs of the reference's own ``compute_pca_features``
+    (src/features/extract_3d_pca_features.py:59), imported from the reference
+    checkout and called on seeded point sets, including its edge cases
+    (planar z == 0, identical points, n == 3, normalize=True, n_bins != 8,
+    far-from-origin clouds).  Keys: pts_<k> float64 [N,3], out_<k> float32,
+    meta_<k> = (n_bins, normalize).
+
+hu_panels.npz
+    Data cut from the run artefacts the reference committed:
+    reports/sample_images/<id>_hu_preview.png are 1120x224 collages written by
+    save_preview (extract_2d_hu.py:510-596); panel 3 (x 672..895) is the
+    preprocessed crop and panel 4 (x 896..1119) is the cleaned 0/255 silhouette
+    of view_01 on which the production run computed Hu.  Stored bit-packed
+    (masks) / as uint8 (gray panels), with the ids.
+
+hu_table_rows.csv
+    The rows of data/features/features_table.csv (12-view mean/std of log-Hu
+    and the PCA columns) for those ids, plus reports/hu_feature_stats.csv and
+    reports/pca_feature_stats.csv copied as hu_feature_stats.csv /
+    pca_feature_stats.csv: distribution-level pins.
+"""
+import argparse
+import importlib
+import os
+import shutil
+import sys
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+
+
+def make_pca(ref: Path) -> None:
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, str(ref / "src" / "features"))
+    mod = importlib.import_module("extract_3d_pca_features")
+    rng = np.random.default_rng(20251010)
+    cases = []
+
+    def add(pts, n_bins=8, normalize=False):
+        pts = np.asarray(pts, dtype=np.float64)
+        cases.append((pts, n_bins, normalize, mod.compute_pca_features(pts, n_bins=n_bins, normalize=normalize)))
+
+    def cloud(n, scales, shift=(0, 0, 0), f32=True):
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        p = (rng.normal(size=(n, 3)) * np.asarray(scales)) @ q.T + np.asarray(shift)
+        # the production inputs are float32 files widened to float64 (load_sample :48-56)
+        return p.astype(np.float32).astype(np.float64) if f32 else p
+
+    for n in (1024, 1024, 1024, 257, 64, 3, 4, 2048, 5000):
+        s = np.exp(rng.uniform(np.log(0.05), np.log(1.0), size=3))
+        add(cloud(n, s))
+    add(cloud(1024, (0.31, 0.10, 0.078)), normalize=True)
+    add(cloud(1024, (0.31, 0.10, 0.078)), n_bins=5)
+    add(cloud(1024, (0.31, 0.10, 0.078)), n_bins=16, normalize=True)
+    add(cloud(1024, (1.0, 0.5, 0.25), shift=(1000.0, -2000.0, 500.0)))
+    planar = cloud(512, (1.0, 0.3, 0.2))
+    planar[:, 2] = 0.0
+    add(planar)
+    add(np.tile(np.array([[0.25, -1.5, 3.0]]), (100, 1)))
+    line = np.zeros((50, 3))
+    line[:, 0] = np.arange(50)
+    add(line)
+    add(np.array([[0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0]]))
+    # integer pixel coordinates (x, y, 0) like the contour point sets
+    ang = np.linspace(0, 2 * np.pi, 400, endpoint=False)
+    ring = np.stack([np.round(200 + 120 * np.cos(ang)), np.round(180 + 60 * np.sin(ang)), 0 * ang], axis=1)
+    add(ring)
+
+    out = {}
+    for k, (pts, nb, nz, vec) in enumerate(cases):
+        out[f"pts_{k}"] = pts
+        out[f"out_{k}"] = vec
+        out[f"meta_{k}"] = np.array([nb, int(nz)], dtype=np.int64)
+    out["n_cases"] = np.array(len(cases))
+    np.savez_compressed(HERE / "pca_golden.npz", **out)
+
+    # error behaviour pinned as data
+    try:
+        mod.compute_pca_features(np.zeros((2, 3)))
+        msg = ""
+    except ValueError as e:
+        msg = str(e)
+    (HERE / "pca_too_few_message.txt").write_text(msg + "\n")
+    print(f"pca_golden.npz: {len(cases)} cases; <3 points -> ValueError({msg!r})")
+
+
+def make_hu(ref: Path) -> None:
+    from PIL import Image
+
+    ids, masks, grays, raws = [], [], [], []
+    for p in sorted((ref / "reports" / "sample_images").glob("*_hu_preview.png")):
+        a = np.asarray(Image.open(p).convert("RGB"))
+        if a.shape != (224, 1120, 3):
+            continue
+        ids.append(p.name[: -len("_hu_preview.png")])
+        mask = a[:, 896:1120, 0]
+        assert set(np.unique(mask)) <= {0, 255}
+        masks.append(np.packbits(mask > 127, axis=1))
+        grays.append(np.asarray(Image.fromarray(a[:, 672:896]).convert("L")))
+        raws.append(np.stack([np.asarray(Image.fromarray(a[:, 224 * k:224 * (k + 1)]).convert("L")) for k in range(3)]))
+    np.savez_compressed(HERE / "hu_panels.npz", ids=np.array(ids), masks_packed=np.stack(masks),
+                        preproc=np.stack(grays), raw_views=np.stack(raws))
+
+    import csv
+    with open(ref / "data" / "features" / "features_table.csv", newline="") as fh:
+        rows = list(csv.reader(fh))
+    keep = [rows[0]] + [r for r in rows[1:] if r[0] in set(ids)]
+    with open(HERE / "hu_table_rows.csv", "w", newline="") as fh:
+        csv.writer(fh).writerows(keep)
+    shutil.copyfile(ref / "reports" / "hu_feature_stats.csv", HERE / "hu_feature_stats.csv")
+    shutil.copyfile(ref / "reports" / "pca_feature_stats.csv", HERE / "pca_feature_stats.csv")
+    print(f"hu_panels.npz: {len(ids)} ids; hu_table_rows.csv: {len(keep) - 1} rows")
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reference", default=os.environ.get("FX_REFERENCE", "/root/reference"))
+    a = ap.parse_args()
+    make_pca(Path(a.reference))
+    make_hu(Path(a.reference))
