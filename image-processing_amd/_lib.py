@@ -1,0 +1,76 @@
+"""ctypes binding of libfx.so (the C ABI declared in include/fx.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails,
+an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("FX_LIB", _HERE / "libfx.so"))
+
+FX_OK = 0
+
+c_void_p = ctypes.c_void_p
+c_int = ctypes.c_int
+c_i64 = ctypes.c_int64
+c_u64 = ctypes.c_uint64
+
+# name -> (restype, argtypes); every symbol include/fx.h declares.
+SIGNATURES = {
+    "fx_init": (c_int, [c_int]),
+    "fx_shutdown": (c_int, []),
+    "fx_last_error": (ctypes.c_char_p, []),
+    "fx_abi_version": (c_int, []),
+    "fx_hu_batch_u8": (c_int, [c_void_p, c_i64, c_int, c_int, c_i64, c_i64, c_int, c_int,
+                               c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "fx_hu_groupstat": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
+    "fx_pca_batch_f32": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_int, c_int, c_int,
+                                 c_void_p, c_void_p, c_void_p]),
+    "fx_synth_shapes_u8": (c_int, [c_void_p, c_i64, c_int, c_int, c_i64, c_i64, c_u64, c_i64, c_void_p]),
+    "fx_synth_points_f32": (c_int, [c_void_p, c_i64, c_i64, c_u64, c_i64, c_void_p]),
+    "fx_profile": (c_int, [c_int]),
+    "fx_profile_last_ms": (ctypes.c_double, []),
+}
+
+
+class FxError(RuntimeError):
+    """A libfx call returned a non-zero status."""
+
+    def __init__(self, fn: str, code: int, message: str):
+        super().__init__(f"{fn} failed with {code}: {message}")
+        self.fn, self.code, self.message = fn, code, message
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Loads libfx.so once and attaches the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `make -C {_HERE / 'csrc'}` "
+            "(or __graft_entry__.build()); this package has no CPU fallback")
+    lib = ctypes.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args):
+    """Calls an int-returning entry point and raises FxError on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != FX_OK:
+        msg = lib.fx_last_error()
+        raise FxError(name, rc, msg.decode("utf-8", "replace") if msg else "")
+    return rc

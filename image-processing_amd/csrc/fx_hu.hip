@@ -1,0 +1,661 @@
+// Hu-moment kernels: fused binarisation + ten raw spatial moments in one
+// coalesced pass over the image, central/normalised moments, the seven Hu
+// invariants, the log transform, and (optionally) the PCA descriptor of the
+// contour pixels out of an LDS-resident bit mask.
+//
+// Replaces the arithmetic of reference src/features/extract_2d_hu.py:443-478
+// (cv2.moments / cv2.HuMoments / log transform) and :641-644 (per-sample
+// mean/std); the contour descriptor applies
+// src/features/extract_3d_pca_features.py:59-145 to contour pixels.
+//
+// Bandwidth-bound integer reduction: 16 B per lane loads, v_dot4_u32_u8 for
+// the in-chunk power sums, 32-bit per-lane partials flushed into 64-bit ones,
+// wave shuffles + LDS for the block reduction.  No MFMA.
+#include "fx_common.h"
+#include "fx_eig.h"
+
+namespace {
+
+// ------------------------------------------------------------------ geometry
+// A block of 256 threads owns one image.  The image is cut into 16-pixel
+// chunks; thread t owns the column strip tx = t % cpr and visits rows
+// ty, ty + R, ty + 2R, ... with ty = t / cpr and R = 256 / cpr rows per pass,
+// so its x offset is fixed and the in-chunk sums can stay in strip-local
+// coordinates until the very end.
+struct HuArgs {
+    const uint8_t *img;
+    int64_t B;
+    int H, W;
+    int64_t pitch, stride;
+    int thresh, on_value;
+    double *moments24;
+    double *hu7;
+    float *hulog7;
+    int n_bins;
+    float *cpca;
+    double *ceig;
+    int cpr;   // 16-pixel chunks per row (last one may be partial)
+    int rpp;   // rows per pass = 256 / cpr
+    int wpr;   // 32-bit mask words per row = ceil(cpr / 2)
+    int wrpp;  // mask rows per pass = 256 / wpr
+};
+
+constexpr int MODE_GRAY = 0;     // weight = pixel value
+constexpr int MODE_BIT7 = 1;     // weight = on_value * (pixel > 127)
+constexpr int MODE_THRESH = 2;   // weight = on_value * (pixel > thresh)
+
+__host__ __device__ constexpr uint32_t pack4(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    return a | (b << 8) | (c << 16) | (d << 24);
+}
+// byte j of dword d of a chunk is pixel i = 4d + j of the chunk
+__host__ __device__ constexpr uint32_t K1(int d) { return pack4(4 * d, 4 * d + 1, 4 * d + 2, 4 * d + 3); }
+__host__ __device__ constexpr uint32_t sq(int i) { return (uint32_t)(i * i); }
+__host__ __device__ constexpr uint32_t cu(int i) { return (uint32_t)(i * i * i); }
+__host__ __device__ constexpr uint32_t K2(int d)
+{
+    return pack4(sq(4 * d), sq(4 * d + 1), sq(4 * d + 2), sq(4 * d + 3));
+}
+__host__ __device__ constexpr uint32_t K3L(int d)
+{
+    return pack4(cu(4 * d) & 255, cu(4 * d + 1) & 255, cu(4 * d + 2) & 255, cu(4 * d + 3) & 255);
+}
+__host__ __device__ constexpr uint32_t K3H(int d)
+{
+    return pack4(cu(4 * d) >> 8, cu(4 * d + 1) >> 8, cu(4 * d + 2) >> 8, cu(4 * d + 3) >> 8);
+}
+
+__device__ __forceinline__ uint32_t dot4(uint32_t a, uint32_t b, uint32_t c)
+{
+    return __builtin_amdgcn_udot4(a, b, c, false);
+}
+
+// 0/1 per byte: byte > t, with k = (255 - t) * 0x00010001.
+__device__ __forceinline__ uint32_t gt_bytes(uint32_t a, uint32_t k)
+{
+    uint32_t e = (a & 0x00FF00FFu) + k;
+    uint32_t o = ((a >> 8) & 0x00FF00FFu) + k;
+    return ((e >> 8) & 0x00010001u) | (o & 0x01000100u);
+}
+
+// Per-lane 32-bit partial sums over up to 32 visited rows j = 0..31 of the
+// strip: a[k][q] = sum_j j^q * s_k(j), s_k = sum_i i^k * w_i over the chunk.
+struct Acc32 {
+    uint32_t a00, a10, a20, a30, a01, a11, a21, a02, a12, a03;
+    __device__ __forceinline__ void clear() { a00 = a10 = a20 = a30 = a01 = a11 = a21 = a02 = a12 = a03 = 0; }
+};
+
+struct Tot64 {
+    u64 t00, t10, t20, t30, t01, t11, t21, t02, t12, t03;
+    __device__ __forceinline__ void clear() { t00 = t10 = t20 = t30 = t01 = t11 = t21 = t02 = t12 = t03 = 0; }
+};
+
+template <int MODE>
+__device__ __forceinline__ void chunk_sums(const uint4 &v, uint32_t kthr, uint32_t j, Acc32 &a,
+                                           uint32_t &bits16)
+{
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t src[4];
+    uint32_t nib[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        if (MODE == MODE_THRESH) {
+            uint32_t m = gt_bytes(w[d], kthr);
+            src[d] = m;
+            nib[d] = (m * 0x01020408u) >> 24;  // bytes 0/1 -> 4 bits
+        } else {
+            uint32_t hi = w[d] & 0x80808080u;
+            src[d] = (MODE == MODE_BIT7) ? (hi >> 7) : w[d];
+            nib[d] = (hi * 0x00204081u) >> 28;  // bit 7 of each byte -> 4 bits
+        }
+    }
+    bits16 = (nib[0] & 15u) | ((nib[1] & 15u) << 4) | ((nib[2] & 15u) << 8) | ((nib[3] & 15u) << 12);
+
+    uint32_t s0 = 0, s1 = 0, s2 = 0, s3l = 0, s3h = 0;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        s0 = dot4(src[d], 0x01010101u, s0);
+        s1 = dot4(src[d], K1(d), s1);
+        s2 = dot4(src[d], K2(d), s2);
+        s3l = dot4(src[d], K3L(d), s3l);
+        s3h = dot4(src[d], K3H(d), s3h);
+    }
+    uint32_t s3 = s3l + (s3h << 8);
+    uint32_t j2 = j * j, j3 = j2 * j;  // j < 32, wave-uniform
+    a.a00 += s0;
+    a.a10 += s1;
+    a.a20 += s2;
+    a.a30 += s3;
+    a.a01 += __umul24(j, s0);
+    a.a11 += __umul24(j, s1);
+    a.a21 += __umul24(j, s2);
+    a.a02 += __umul24(j2, s0);
+    a.a12 += __umul24(j2, s1);
+    a.a03 += __umul24(j3, s0);
+}
+
+// Rows visited are y = y0 + R*j; fold the strip-local 32-bit sums into the
+// 64-bit sums over y (x still strip-local).
+__device__ __forceinline__ void flush(const Acc32 &a, u64 y0, u64 R, Tot64 &t)
+{
+    u64 y02 = y0 * y0, R2 = R * R;
+    t.t00 += a.a00;
+    t.t10 += a.a10;
+    t.t20 += a.a20;
+    t.t30 += a.a30;
+    t.t01 += y0 * a.a00 + R * a.a01;
+    t.t11 += y0 * a.a10 + R * a.a11;
+    t.t21 += y0 * a.a20 + R * a.a21;
+    t.t02 += y02 * a.a00 + 2 * y0 * R * a.a01 + R2 * a.a02;
+    t.t12 += y02 * a.a10 + 2 * y0 * R * a.a11 + R2 * a.a12;
+    t.t03 += y02 * y0 * a.a00 + 3 * y02 * R * a.a01 + 3 * y0 * R2 * a.a02 + R2 * R * a.a03;
+}
+
+// Sum NV 64-bit values over the block; every thread gets the totals.  red is
+// LDS with room for FX_WAVES_PER_BLOCK * NV u64.
+template <int NV>
+__device__ __forceinline__ void block_sum_u64(u64 (&v)[NV], u64 *red)
+{
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            v[k] += (u64)__shfl_down((unsigned long long)v[k], o, FX_WAVE);
+    }
+    if (fx_lane() == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; k++)
+            red[fx_wave() * NV + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        u64 s = 0;
+#pragma unroll
+        for (int w = 0; w < FX_WAVES_PER_BLOCK; w++)
+            s += red[w * NV + k];
+        v[k] = s;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ double block_max_f64(double v, double *red)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v = fmax(v, __shfl_down(v, o, FX_WAVE));
+    if (fx_lane() == 0)
+        red[fx_wave()] = v;
+    __syncthreads();
+    double m = red[0];
+#pragma unroll
+    for (int w = 1; w < FX_WAVES_PER_BLOCK; w++)
+        m = fmax(m, red[w]);
+    __syncthreads();
+    return m;
+}
+
+// OpenCV completeMomentState + HuMoments + the reference's log transform, in
+// IEEE double without contraction, operation order kept.
+__device__ void finalize_moments(const double (&raw)[10], double *moments24, double *hu7, float *hulog7)
+{
+    const double m00 = raw[0], m10 = raw[1], m01 = raw[2], m20 = raw[3], m11 = raw[4];
+    const double m02 = raw[5], m30 = raw[6], m21 = raw[7], m12 = raw[8], m03 = raw[9];
+    double cx = 0.0, cy = 0.0, inv_m00 = 0.0;
+    if (fabs(m00) > 2.220446049250313e-16) {
+        inv_m00 = 1.0 / m00;
+        cx = m10 * inv_m00;
+        cy = m01 * inv_m00;
+    }
+    double mu20 = m20 - m10 * cx;
+    double mu11 = m11 - m10 * cy;
+    double mu02 = m02 - m01 * cy;
+    double mu30 = m30 - cx * (3 * mu20 + cx * m10);
+    double mu11x2 = mu11 + mu11;
+    double mu21 = m21 - cx * (mu11x2 + cx * m01) - cy * mu20;
+    double mu12 = m12 - cy * (mu11x2 + cy * m10) - cx * mu02;
+    double mu03 = m03 - cy * (3 * mu02 + cy * m01);
+
+    double inv_sqrt_m00 = sqrt(fabs(inv_m00));
+    double s2 = inv_m00 * inv_m00, s3 = s2 * inv_sqrt_m00;
+    double nu20 = mu20 * s2, nu11 = mu11 * s2, nu02 = mu02 * s2;
+    double nu30 = mu30 * s3, nu21 = mu21 * s3, nu12 = mu12 * s3, nu03 = mu03 * s3;
+
+    if (moments24) {
+#pragma unroll
+        for (int k = 0; k < 10; k++)
+            moments24[k] = raw[k];
+        moments24[10] = mu20;
+        moments24[11] = mu11;
+        moments24[12] = mu02;
+        moments24[13] = mu30;
+        moments24[14] = mu21;
+        moments24[15] = mu12;
+        moments24[16] = mu03;
+        moments24[17] = nu20;
+        moments24[18] = nu11;
+        moments24[19] = nu02;
+        moments24[20] = nu30;
+        moments24[21] = nu21;
+        moments24[22] = nu12;
+        moments24[23] = nu03;
+    }
+
+    double hu[7];
+    double t0 = nu30 + nu12;
+    double t1 = nu21 + nu03;
+    double q0 = t0 * t0, q1 = t1 * t1;
+    double n4 = 4 * nu11;
+    double s = nu20 + nu02;
+    double d = nu20 - nu02;
+    hu[0] = s;
+    hu[1] = d * d + n4 * nu11;
+    hu[3] = q0 + q1;
+    hu[5] = d * (q0 - q1) + n4 * t0 * t1;
+    t0 *= q0 - 3 * q1;
+    t1 *= 3 * q0 - q1;
+    q0 = nu30 - 3 * nu12;
+    q1 = 3 * nu21 - nu03;
+    hu[2] = q0 * q0 + q1 * q1;
+    hu[4] = q0 * t0 + q1 * t1;
+    hu[6] = q1 * t0 - q0 * t1;
+
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        if (hu7)
+            hu7[i] = hu[i];
+        if (hulog7) {
+            double h = hu[i];
+            double v = 0.0;
+            if (h > 0.0)
+                v = -log10(h + 1e-300);
+            else if (h < 0.0)
+                v = log10(-h + 1e-300);
+            if (isinf(v) || isnan(v))
+                v = 0.0;
+            hulog7[i] = (float)v;
+        }
+    }
+}
+
+// Contour words: bit i of word (y, wx) is pixel (32*wx + i, y).  mask holds
+// H + 2 rows (a zero row above and below) of wpr words.
+__device__ __forceinline__ uint32_t contour_word(const uint32_t *mask, int wpr, int y, int wx)
+{
+    const uint32_t *row = mask + (y + 1) * wpr;
+    uint32_t c = row[wx];
+    uint32_t up = row[wx - wpr];
+    uint32_t dn = row[wx + wpr];
+    uint32_t lbit = wx > 0 ? (row[wx - 1] >> 31) : 0u;
+    uint32_t rbit = wx < wpr - 1 ? (row[wx + 1] & 1u) : 0u;
+    uint32_t left = (c << 1) | lbit;
+    uint32_t right = (c >> 1) | (rbit << 31);
+    return c & ~(up & dn & left & right);
+}
+
+constexpr int LDS_RED_BYTES = 1024;   // block reduction scratch (u64 / double)
+constexpr int LDS_BCAST_BYTES = 128;  // doubles broadcast from thread 0
+constexpr int LDS_HIST_BYTES = 256;   // 64 x u32 histogram
+constexpr int LDS_HEAD_BYTES = LDS_RED_BYTES + LDS_BCAST_BYTES + LDS_HIST_BYTES;
+
+template <int MODE, bool CONTOUR, bool ALIGNED>
+__global__ __launch_bounds__(FX_BLOCK) void hu_image_kernel(HuArgs A)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    u64 *red = reinterpret_cast<u64 *>(lds_raw);
+    double *bcast = reinterpret_cast<double *>(lds_raw + LDS_RED_BYTES);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(lds_raw + LDS_RED_BYTES + LDS_BCAST_BYTES);
+    uint32_t *mask = reinterpret_cast<uint32_t *>(lds_raw + LDS_HEAD_BYTES);
+
+    const int t = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    const uint8_t *img = A.img + b * A.stride;
+    const int H = A.H, W = A.W;
+
+    if (CONTOUR) {
+        const int words = (H + 2) * A.wpr;
+        for (int i = t; i < words; i += FX_BLOCK)
+            mask[i] = 0;
+        if (t < 64)
+            hist[t] = 0;
+        __syncthreads();
+    }
+
+    // ---- pass 1: one read of the image -----------------------------------
+    const int ty = t / A.cpr, tx = t - ty * A.cpr;
+    const int R = A.rpp;
+    const int x0 = tx * 16;
+    const uint32_t kthr = (uint32_t)(255 - (A.thresh < 0 ? 127 : A.thresh)) * 0x00010001u;
+    Tot64 T;
+    T.clear();
+
+    if (ty < R) {
+        const bool full = ALIGNED && (x0 + 16 <= W);
+        uint16_t *mask16 = reinterpret_cast<uint16_t *>(mask);
+        auto load_chunk = [&](int y) -> uint4 {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (y < H) {
+                const uint8_t *p = img + (int64_t)y * A.pitch + x0;
+                if (full) {
+                    v = *reinterpret_cast<const uint4 *>(p);
+                } else {
+                    uint32_t w[4] = {0, 0, 0, 0};
+                    int n = W - x0;
+                    n = n > 16 ? 16 : n;
+                    for (int k = 0; k < n; k++)
+                        w[k >> 2] |= (uint32_t)p[k] << (8 * (k & 3));
+                    v = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+            }
+            return v;
+        };
+        auto put_bits = [&](int y, uint32_t bits) {
+            if (CONTOUR && y < H)
+                mask16[((y + 1) * A.wpr) * 2 + tx] = (uint16_t)bits;
+        };
+
+        for (int y = ty; y < H;) {
+            Acc32 a;
+            a.clear();
+            const int y0 = y;
+#pragma unroll 1
+            for (int j = 0; j < 32 && y < H; j += 4, y += 4 * R) {
+                uint4 v0 = load_chunk(y);
+                uint4 v1 = load_chunk(y + R);
+                uint4 v2 = load_chunk(y + 2 * R);
+                uint4 v3 = load_chunk(y + 3 * R);
+                uint32_t b0, b1, b2, b3;
+                chunk_sums<MODE>(v0, kthr, j, a, b0);
+                chunk_sums<MODE>(v1, kthr, j + 1, a, b1);
+                chunk_sums<MODE>(v2, kthr, j + 2, a, b2);
+                chunk_sums<MODE>(v3, kthr, j + 3, a, b3);
+                put_bits(y, b0);
+                put_bits(y + R, b1);
+                put_bits(y + 2 * R, b2);
+                put_bits(y + 3 * R, b3);
+            }
+            flush(a, (u64)y0, (u64)R, T);
+        }
+    }
+
+    // strip-local x -> image x
+    u64 M[10];
+    {
+        const u64 X = (u64)x0, X2 = X * X, X3 = X2 * X;
+        M[0] = T.t00;
+        M[1] = X * T.t00 + T.t10;
+        M[2] = T.t01;
+        M[3] = X2 * T.t00 + 2 * X * T.t10 + T.t20;
+        M[4] = X * T.t01 + T.t11;
+        M[5] = T.t02;
+        M[6] = X3 * T.t00 + 3 * X2 * T.t10 + 3 * X * T.t20 + T.t30;
+        M[7] = X2 * T.t01 + 2 * X * T.t11 + T.t21;
+        M[8] = X * T.t02 + T.t12;
+        M[9] = T.t03;
+    }
+    block_sum_u64<10>(M, red);  // includes the barrier that completes the mask
+
+    if (t == 0) {
+        const u64 scale = (MODE == MODE_GRAY) ? 1ull : (u64)A.on_value;
+        double raw[10];
+#pragma unroll
+        for (int k = 0; k < 10; k++)
+            raw[k] = (double)(M[k] * scale);
+        finalize_moments(raw, A.moments24 ? A.moments24 + b * 24 : nullptr,
+                         A.hu7 ? A.hu7 + b * 7 : nullptr, A.hulog7 ? A.hulog7 + b * 7 : nullptr);
+    }
+
+    if (!CONTOUR)
+        return;
+
+    // ---- contour descriptor out of the LDS bit mask ------------------------
+    const int nb = A.n_bins;
+    const int wy = t / A.wpr, wx = t - wy * A.wpr;
+    const int WR = A.wrpp;
+    const bool wactive = wy < WR;
+    const int X0 = wx * 32;
+
+    // sums over contour pixels: n, sum x, sum y, sum x^2, sum xy, sum y^2
+    u64 S[6] = {0, 0, 0, 0, 0, 0};
+    if (wactive) {
+        u64 c0 = 0, c1 = 0, cy = 0, c2 = 0, cxy = 0, cyy = 0;  // x word-local
+        for (int y = wy; y < H; y += WR) {
+            uint32_t bw = contour_word(mask, A.wpr, y, wx);
+            if (bw == 0)
+                continue;
+            uint32_t p0 = __popc(bw & 0xAAAAAAAAu), p1 = __popc(bw & 0xCCCCCCCCu);
+            uint32_t p2 = __popc(bw & 0xF0F0F0F0u), p3 = __popc(bw & 0xFF00FF00u);
+            uint32_t p4 = __popc(bw & 0xFFFF0000u);
+            uint32_t r0 = __popc(bw);
+            uint32_t r1 = p0 + 2 * p1 + 4 * p2 + 8 * p3 + 16 * p4;
+            // sum i^2 = sum_k 4^k p_k + sum_{j<k} 2^(j+k+1) popc(b & M_j & M_k)
+            uint32_t r2 = p0 + 4 * p1 + 16 * p2 + 64 * p3 + 256 * p4;
+            r2 += 4 * __popc(bw & 0xAAAAAAAAu & 0xCCCCCCCCu);
+            r2 += 8 * __popc(bw & 0xAAAAAAAAu & 0xF0F0F0F0u);
+            r2 += 16 * __popc(bw & 0xAAAAAAAAu & 0xFF00FF00u);
+            r2 += 32 * __popc(bw & 0xAAAAAAAAu & 0xFFFF0000u);
+            r2 += 16 * __popc(bw & 0xCCCCCCCCu & 0xF0F0F0F0u);
+            r2 += 32 * __popc(bw & 0xCCCCCCCCu & 0xFF00FF00u);
+            r2 += 64 * __popc(bw & 0xCCCCCCCCu & 0xFFFF0000u);
+            r2 += 64 * __popc(bw & 0xF0F0F0F0u & 0xFF00FF00u);
+            r2 += 128 * __popc(bw & 0xF0F0F0F0u & 0xFFFF0000u);
+            r2 += 256 * __popc(bw & 0xFF00FF00u & 0xFFFF0000u);
+            const u64 Y = (u64)y;
+            c0 += r0;
+            c1 += r1;
+            c2 += r2;
+            cy += Y * r0;
+            cxy += Y * r1;
+            cyy += Y * Y * r0;
+        }
+        const u64 X = (u64)X0;
+        S[0] = c0;
+        S[1] = X * c0 + c1;
+        S[2] = cy;
+        S[3] = X * X * c0 + 2 * X * c1 + c2;
+        S[4] = X * cy + cxy;
+        S[5] = cyy;
+    }
+    block_sum_u64<6>(S, red);
+
+    const u64 n = S[0];
+    const int64_t row = b * (9 + nb);
+    if (n < 3) {
+        const float nanv = __builtin_nanf("");
+        for (int i = t; i < 9 + nb; i += FX_BLOCK)
+            A.cpca[row + i] = nanv;
+        if (A.ceig && t < 6)
+            A.ceig[b * 6 + t] = __builtin_nan("");
+        return;
+    }
+
+    if (t == 0) {
+        // covariance (ddof = 1) from exact integer sums: n*Sxx - Sx^2 etc.
+        const double dn = (double)n;
+        const double inv = 1.0 / (dn * (double)(n - 1));
+        const i64 sx = (i64)S[1], sy = (i64)S[2];
+        const double cxx = (double)((i64)(n * S[3]) - sx * sx) * inv;
+        const double cxy = (double)((i64)(n * S[4]) - sx * sy) * inv;
+        const double cyy = (double)((i64)(n * S[5]) - sy * sy) * inv;
+        double lam[3], v1[3], head[9];
+        fx_eig3(cxx, cxy, 0.0, cyy, 0.0, 0.0, lam, v1);
+        fx_pca_head(lam, head);
+        for (int i = 0; i < 9; i++)
+            A.cpca[row + i] = (float)head[i];
+        if (A.ceig) {
+            for (int i = 0; i < 3; i++) {
+                A.ceig[b * 6 + i] = lam[i];
+                A.ceig[b * 6 + 3 + i] = v1[i];
+            }
+        }
+        bcast[0] = (double)S[1] / dn;  // centroid
+        bcast[1] = (double)S[2] / dn;
+        bcast[2] = v1[0];
+        bcast[3] = v1[1];
+    }
+    __syncthreads();
+    const double ccx = bcast[0], ccy = bcast[1], vx = bcast[2], vy = bcast[3];
+
+    // |projection on PC1| is monotone in x along a row, so the largest value
+    // in a word is at its lowest or highest set bit.
+    double top = 0.0;
+    if (wactive) {
+        for (int y = wy; y < H; y += WR) {
+            uint32_t bw = contour_word(mask, A.wpr, y, wx);
+            if (bw == 0)
+                continue;
+            const double dy = (double)y - ccy;
+            const int lo = __ffs((int)bw) - 1, hi = 31 - __clz((int)bw);
+            const double plo = fabs(fma(dy, vy, ((double)(X0 + lo) - ccx) * vx));
+            const double phi = fabs(fma(dy, vy, ((double)(X0 + hi) - ccx) * vx));
+            top = fmax(top, fmax(plo, phi));
+        }
+    }
+    top = block_max_f64(top, reinterpret_cast<double *>(red));
+
+    if (top > 0.0) {
+        const double step = top / (double)nb;
+        const double inv_step = (double)nb / top;
+        if (wactive) {
+            for (int y = wy; y < H; y += WR) {
+                uint32_t bw = contour_word(mask, A.wpr, y, wx);
+                const double dy = (double)y - ccy;
+                while (bw) {
+                    const int i = __ffs((int)bw) - 1;
+                    bw &= bw - 1;
+                    const double p = fabs(fma(dy, vy, ((double)(X0 + i) - ccx) * vx));
+                    atomicAdd(&hist[fx_hist_bin(p, step, inv_step, nb)], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        if (t < nb)
+            A.cpca[row + 9 + t] = (float)((double)hist[t] / (double)n);
+    } else if (t < nb) {
+        A.cpca[row + 9 + t] = t == 0 ? 1.0f : 0.0f;
+    }
+}
+
+__global__ void hu_groupstat_kernel(const float *hulog7, const int64_t *offsets, int64_t G, float *out14)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= G * 7)
+        return;
+    const int64_t g = i / 7;
+    const int j = (int)(i - g * 7);
+    const int64_t a = offsets[g], b = offsets[g + 1];
+    const float cnt = (float)(b - a);
+    float s = 0.0f;
+    for (int64_t r = a; r < b; r++)
+        s = s + hulog7[r * 7 + j];
+    const float mean = s / cnt;
+    float q = 0.0f;
+    for (int64_t r = a; r < b; r++) {
+        const float d = hulog7[r * 7 + j] - mean;
+        q = q + d * d;
+    }
+    out14[g * 14 + j] = mean;
+    out14[g * 14 + 7 + j] = sqrtf(q / cnt);
+}
+
+template <int MODE, bool CONTOUR>
+int launch_image_kernel(const HuArgs &A, bool aligned, size_t lds, hipStream_t s)
+{
+    dim3 grid((unsigned)A.B), block(FX_BLOCK);
+    if (aligned) {
+        auto k = hu_image_kernel<MODE, CONTOUR, true>;
+        if (lds > 48 * 1024)
+            FX_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k, grid, block, lds, s, A);
+    } else {
+        auto k = hu_image_kernel<MODE, CONTOUR, false>;
+        if (lds > 48 * 1024)
+            FX_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k, grid, block, lds, s, A);
+    }
+    FX_HIP_CHECK(hipGetLastError());
+    return FX_OK;
+}
+
+}  // namespace
+
+extern "C" int fx_hu_batch_u8(const uint8_t *d_img, int64_t B, int H, int W, int64_t pitch_bytes,
+                              int64_t img_stride_bytes, int thresh, int on_value, double *d_moments24,
+                              double *d_hu7, float *d_hulog7, int n_bins, float *d_cpca, double *d_ceig,
+                              void *stream)
+{
+    FX_REQUIRE(B >= 0, "fx_hu_batch_u8: B = %lld", (long long)B);
+    if (B == 0)
+        return FX_OK;
+    FX_REQUIRE(d_img != nullptr, "fx_hu_batch_u8: d_img is NULL");
+    FX_REQUIRE(H >= 1 && W >= 1 && H <= 16384 && W <= 16384, "fx_hu_batch_u8: image %d x %d outside 1..16384", H, W);
+    FX_REQUIRE(pitch_bytes >= W, "fx_hu_batch_u8: pitch %lld < width %d", (long long)pitch_bytes, W);
+    FX_REQUIRE(B == 1 || img_stride_bytes >= pitch_bytes * (int64_t)(H - 1) + W,
+               "fx_hu_batch_u8: image stride %lld overlaps images", (long long)img_stride_bytes);
+    FX_REQUIRE(thresh < 255, "fx_hu_batch_u8: thresh %d must be < 255 (or negative)", thresh);
+    FX_REQUIRE(thresh < 0 || (on_value >= 1 && on_value <= 255), "fx_hu_batch_u8: on_value %d outside 1..255", on_value);
+    FX_REQUIRE(d_moments24 || d_hu7 || d_hulog7 || d_cpca, "fx_hu_batch_u8: no output requested");
+    FX_REQUIRE(!d_cpca || (n_bins >= 1 && n_bins <= 64), "fx_hu_batch_u8: n_bins %d outside 1..64", n_bins);
+    FX_REQUIRE(d_cpca || !d_ceig, "fx_hu_batch_u8: d_ceig needs d_cpca");
+    FX_REQUIRE(B <= 0x7fffffffLL, "fx_hu_batch_u8: B too large for one launch");
+
+    hipStream_t s = (hipStream_t)stream;
+    HuArgs A;
+    A.img = d_img;
+    A.B = B;
+    A.H = H;
+    A.W = W;
+    A.pitch = pitch_bytes;
+    A.stride = img_stride_bytes;
+    A.thresh = thresh;
+    A.on_value = on_value;
+    A.moments24 = d_moments24;
+    A.hu7 = d_hu7;
+    A.hulog7 = d_hulog7;
+    A.n_bins = n_bins;
+    A.cpca = d_cpca;
+    A.ceig = d_ceig;
+    A.cpr = (W + 15) / 16;
+    A.wpr = (A.cpr + 1) / 2;
+
+    const bool contour = d_cpca != nullptr;
+    const size_t mask_bytes = contour ? (size_t)(H + 2) * A.wpr * 4 : 0;
+    const bool single_block = W <= 2048 && H <= 2048 && mask_bytes <= 128 * 1024;
+    if (!single_block) {
+        fx_set_error("fx_hu_batch_u8: images larger than 2048 x 2048 (or contour masks over 128 KiB) are not supported yet");
+        return FX_EINVAL;
+    }
+    A.rpp = FX_BLOCK / A.cpr;
+    A.wrpp = FX_BLOCK / A.wpr;
+    const bool aligned = ((uintptr_t)d_img % 16 == 0) && (pitch_bytes % 16 == 0) && (img_stride_bytes % 16 == 0 || B == 1);
+    const size_t lds = LDS_HEAD_BYTES + mask_bytes;
+    const int mode = thresh < 0 ? MODE_GRAY : (thresh == 127 ? MODE_BIT7 : MODE_THRESH);
+
+    FxProfileScope prof(s);
+    int rc;
+    if (contour) {
+        rc = mode == MODE_GRAY   ? launch_image_kernel<MODE_GRAY, true>(A, aligned, lds, s)
+             : mode == MODE_BIT7 ? launch_image_kernel<MODE_BIT7, true>(A, aligned, lds, s)
+                                 : launch_image_kernel<MODE_THRESH, true>(A, aligned, lds, s);
+    } else {
+        rc = mode == MODE_GRAY   ? launch_image_kernel<MODE_GRAY, false>(A, aligned, lds, s)
+             : mode == MODE_BIT7 ? launch_image_kernel<MODE_BIT7, false>(A, aligned, lds, s)
+                                 : launch_image_kernel<MODE_THRESH, false>(A, aligned, lds, s);
+    }
+    return rc;
+}
+
+extern "C" int fx_hu_groupstat(const float *d_hulog7, const int64_t *d_group_offsets, int64_t G, float *d_out14,
+                               void *stream)
+{
+    FX_REQUIRE(G >= 0, "fx_hu_groupstat: G = %lld", (long long)G);
+    if (G == 0)
+        return FX_OK;
+    FX_REQUIRE(d_hulog7 && d_group_offsets && d_out14, "fx_hu_groupstat: NULL argument");
+    const int64_t n = G * 7;
+    FX_REQUIRE((n + 255) / 256 <= 0x7fffffffLL, "fx_hu_groupstat: G too large");
+    hipLaunchKernelGGL(hu_groupstat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       d_hulog7, d_group_offsets, G, d_out14);
+    FX_HIP_CHECK(hipGetLastError());
+    return FX_OK;
+}

@@ -1,0 +1,60 @@
+"""Sharding of independent units (images, point sets, files) across ranks and
+the single collective of the path: an all-gather of the per-rank feature block.
+
+Every unit is independent, so the data path has no exchange step; one rank
+owns one GPU (one process per GPU, torch.distributed over RCCL on the GPU box,
+gloo in CPU tests).  Shards are contiguous blocks of the sorted unit list, the
+reference's deterministic lexicographic order
+(extract_2d_hu.py:75, extract_3d_pca_features.py:318-320).
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_units: int, rank: int, world: int) -> Tuple[int, int]:
+    """[lo, hi) of rank's contiguous block: ceil(n/world) units per rank, the
+    last ranks may get fewer (or none)."""
+    per = -(-n_units // world) if world > 0 else n_units
+    lo = min(n_units, rank * per)
+    return lo, min(n_units, lo + per)
+
+
+def shard_sizes(n_units: int, world: int) -> List[int]:
+    return [hi - lo for lo, hi in (shard_range(n_units, r, world) for r in range(world))]
+
+
+def lpt_assign(costs: Sequence[float], world: int) -> List[List[int]]:
+    """Longest-processing-time-first assignment of units with unequal cost
+    (variable-size clouds): returns the unit indices per rank."""
+    order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+    loads = [0.0] * world
+    out: List[List[int]] = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (loads[k], k))
+        out[r].append(i)
+        loads[r] += costs[i]
+    return [sorted(v) for v in out]
+
+
+def all_gather_rows(local: torch.Tensor, n_units: int) -> torch.Tensor:
+    """Gathers the per-rank [rows_r, F] blocks of a contiguous sharding of
+    n_units rows into the [n_units, F] table on every rank.  Without an
+    initialised process group (single process) returns `local`."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local
+    world, rank = dist.get_world_size(), dist.get_rank()
+    per = -(-n_units // world)
+    F = local.shape[1]
+    lo, hi = shard_range(n_units, rank, world)
+    if local.shape[0] != hi - lo:
+        raise ValueError(f"rank {rank} holds {local.shape[0]} rows, its shard has {hi - lo}")
+    # equal-sized slots so that one all_gather_into_tensor moves everything
+    slot = torch.zeros((per, F), dtype=local.dtype, device=local.device)
+    slot[: hi - lo] = local
+    table = torch.empty((world * per, F), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(table, slot)
+    return table[:n_units]

@@ -1,0 +1,161 @@
+"""Device-level batch API: torch tensors carry the buffers, libfx does the work.
+
+Every function here enqueues HIP kernels on torch's current stream of the
+tensor's device and returns torch tensors that live on that device.  Nothing is
+computed on the host.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+HU_COLS = 7
+MOMENT_COLS = 24
+
+
+def _require_cuda(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise ValueError(f"{name} must be a device tensor (got {t.device}); this engine has no CPU path")
+
+
+_initialised = set()
+
+
+def _enter(device: torch.device) -> int:
+    """Makes `device` current for HIP and returns torch's current stream handle on it."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    torch.cuda.set_device(idx)
+    if idx not in _initialised:
+        _lib.call("fx_init", idx)
+        _initialised.add(idx)
+    return int(torch.cuda.current_stream(idx).cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def hu_batch(images: torch.Tensor, thresh: int = -1, on_value: int = 255, *, moments: bool = False,
+             hu: bool = False, contour_bins: Optional[int] = None, contour_eig: bool = False) -> dict:
+    """Log-Hu vectors of a batch of uint8 images [B, H, W] (rows may be padded:
+    any strides with a unit inner stride are accepted).
+
+    Returns {"hulog7": f32 [B,7]} plus, on request, "moments24" f64 [B,24]
+    (the cv2.moments record), "hu7" f64 [B,7], "cpca" f32 [B, 9+contour_bins]
+    (PCA descriptor of the contour pixels) and "ceig" f64 [B,6].
+    """
+    _require_cuda(images, "images")
+    if images.dtype != torch.uint8 or images.dim() != 3:
+        raise ValueError(f"images must be uint8 [B, H, W], got {images.dtype} {tuple(images.shape)}")
+    if images.stride(2) != 1 and images.shape[2] > 1:
+        raise ValueError("images must have a unit stride along the row")
+    stream = _enter(images.device)
+    B, H, W = images.shape
+    dev = images.device
+    out = {"hulog7": torch.empty((B, HU_COLS), dtype=torch.float32, device=dev)}
+    if moments:
+        out["moments24"] = torch.empty((B, MOMENT_COLS), dtype=torch.float64, device=dev)
+    if hu:
+        out["hu7"] = torch.empty((B, HU_COLS), dtype=torch.float64, device=dev)
+    nb = 0
+    if contour_bins is not None:
+        nb = int(contour_bins)
+        out["cpca"] = torch.empty((B, 9 + nb), dtype=torch.float32, device=dev)
+        if contour_eig:
+            out["ceig"] = torch.empty((B, 6), dtype=torch.float64, device=dev)
+    if B == 0:
+        return out
+    pitch = images.stride(1) if H > 1 else W
+    stride = images.stride(0) if B > 1 else pitch * H
+    _lib.call("fx_hu_batch_u8", images.data_ptr(), B, H, W, pitch, stride, int(thresh), int(on_value),
+              _ptr(out.get("moments24")), _ptr(out.get("hu7")), out["hulog7"].data_ptr(), nb,
+              _ptr(out.get("cpca")), _ptr(out.get("ceig")), stream)
+    return out
+
+
+def hu_groupstat(hulog7: torch.Tensor, group_offsets: torch.Tensor) -> torch.Tensor:
+    """mean || std (ddof=0, float32) of the rows of each group -> f32 [G, 14]."""
+    _require_cuda(hulog7, "hulog7")
+    _require_cuda(group_offsets, "group_offsets")
+    if hulog7.dtype != torch.float32 or hulog7.dim() != 2 or hulog7.shape[1] != HU_COLS or not hulog7.is_contiguous():
+        raise ValueError("hulog7 must be contiguous float32 [rows, 7]")
+    if group_offsets.dtype != torch.int64 or group_offsets.dim() != 1 or group_offsets.numel() < 1:
+        raise ValueError("group_offsets must be int64 [G+1]")
+    stream = _enter(hulog7.device)
+    G = group_offsets.numel() - 1
+    out = torch.empty((G, 2 * HU_COLS), dtype=torch.float32, device=hulog7.device)
+    _lib.call("fx_hu_groupstat", hulog7.data_ptr(), group_offsets.contiguous().data_ptr(), G, out.data_ptr(), stream)
+    return out
+
+
+def pca_batch(points: torch.Tensor, offsets: Optional[torch.Tensor] = None, n_bins: int = 8,
+              normalize: bool = False, *, eig: bool = False) -> dict:
+    """PCA descriptors of point sets.
+
+    points: float32 [B, N, D] (equal-size sets) or, with `offsets` (int64 [B+1]
+    point offsets on the device), float32 [total_points, D]; D is 2 or 3.
+    Returns {"out": f32 [B, 9+n_bins]} and, with eig=True, "eig" f64 [B,6]
+    (lambda1..3, v1).  Sets with fewer than 3 points yield NaN rows.
+    """
+    _require_cuda(points, "points")
+    if points.dtype != torch.float32 or not points.is_contiguous():
+        raise ValueError("points must be contiguous float32")
+    stream = _enter(points.device)
+    if offsets is None:
+        if points.dim() != 3:
+            raise ValueError("points must be [B, N, D] when offsets is None")
+        B, N, D = points.shape
+        off_ptr = None
+    else:
+        _require_cuda(offsets, "offsets")
+        if points.dim() != 2 or offsets.dtype != torch.int64 or offsets.dim() != 1:
+            raise ValueError("ragged input needs points [total, D] and int64 offsets [B+1]")
+        offsets = offsets.contiguous()
+        B, N, D = offsets.numel() - 1, 0, points.shape[1]
+        off_ptr = offsets.data_ptr()
+    res = {"out": torch.empty((B, 9 + int(n_bins)), dtype=torch.float32, device=points.device)}
+    if eig:
+        res["eig"] = torch.empty((B, 6), dtype=torch.float64, device=points.device)
+    if B == 0:
+        return res
+    _lib.call("fx_pca_batch_f32", points.data_ptr(), off_ptr, B, N, D, int(n_bins), int(bool(normalize)),
+              res["out"].data_ptr(), _ptr(res.get("eig")), stream)
+    return res
+
+
+def synth_shapes(B: int, H: int, W: int, seed: int = 42, first_index: int = 0, device="cuda",
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """B synthetic {0,255} shape images generated on the device."""
+    dev = torch.device(device)
+    if out is None:
+        out = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+    _require_cuda(out, "out")
+    stream = _enter(out.device)
+    if B:
+        _lib.call("fx_synth_shapes_u8", out.data_ptr(), B, H, W, out.stride(1), out.stride(0), int(seed),
+                  int(first_index), stream)
+    return out
+
+
+def synth_points(B: int, N: int, seed: int = 42, first_index: int = 0, device="cuda") -> torch.Tensor:
+    """B synthetic Gaussian clouds [B, N, 3] float32 generated on the device."""
+    out = torch.empty((B, N, 3), dtype=torch.float32, device=torch.device(device))
+    _require_cuda(out, "out")
+    stream = _enter(out.device)
+    if B and N:
+        _lib.call("fx_synth_points_f32", out.data_ptr(), B, N, int(seed), int(first_index), stream)
+    return out
+
+
+def profile(enable: bool) -> None:
+    """Switches HIP-event timing of the library's launches on or off."""
+    _lib.call("fx_profile", int(bool(enable)))
+
+
+def profile_last_ms() -> float:
+    """Milliseconds the kernels of the last hu_batch / pca_batch call took
+    (waits for them); negative when profiling was off."""
+    return float(_lib.load().fx_profile_last_ms())

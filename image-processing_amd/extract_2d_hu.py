@@ -1,0 +1,438 @@
+"""Hu-moment feature extraction on MI355X behind the reference's function names.
+
+Mirrors reference src/features/extract_2d_hu.py: same function names, argument
+meaning, return shapes, CSV/.npy layout and error policy.  The arithmetic of
+compute_hu_from_image (:443-478: cv2.moments, cv2.HuMoments, log transform) and
+of the per-sample mean/std (:641-644) runs in the HIP kernels of libfx
+(csrc/fx_hu.hip); there is no CPU fallback for it.
+
+Image decoding and the silhouette preprocessing (Otsu, crop, resize, mask
+cleaning, :84-440) stay on the host here and follow the code path the
+reference itself takes when OpenCV is not installed (PIL + scipy.ndimage),
+which is the only one of its two paths that can be run and checked in an
+environment without cv2.
+
+Added next to the reference API: `compute_hu_batch` and `process_samples`,
+which push many views through one kernel launch.
+"""
+from __future__ import annotations
+
+import argparse
+import datetime
+import logging
+import sys
+from pathlib import Path
+from typing import Any, Dict, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+from PIL import Image, ImageFilter, ImageOps
+
+try:
+    from scipy import ndimage as ndi
+    _HAS_NDIMAGE = True
+except Exception:  # pragma: no cover
+    ndi = None
+    _HAS_NDIMAGE = False
+
+logger = logging.getLogger("extract_2d_hu")
+
+IMAGE_SUFFIXES = (".png", ".jpg", ".jpeg")
+HU_COLS = ["id"] + [f"hu{i + 1}_mean" for i in range(7)] + [f"hu{i + 1}_std" for i in range(7)] + ["note"]
+
+
+def ensure_dir(p: Path) -> None:
+    p.mkdir(parents=True, exist_ok=True)
+
+
+def list_sample_ids(views_dir: Path) -> List[Tuple[str, Path]]:
+    """(id, dir) of every sub-directory holding images, sorted by path (reference :66-81)."""
+    found = []
+    if not views_dir.exists():
+        return found
+    for d in sorted(views_dir.iterdir(), key=lambda p: str(p)):
+        if d.is_dir() and any(p.suffix.lower() in IMAGE_SUFFIXES for p in d.glob("*")):
+            found.append((d.name, d))
+    return found
+
+
+def list_view_files(dir_path: Path) -> List[Path]:
+    return sorted((p for p in dir_path.glob("*") if p.suffix.lower() in IMAGE_SUFFIXES), key=lambda p: str(p))
+
+
+def load_image(path: Path) -> np.ndarray:
+    """Grayscale uint8 array of an image file (reference :84-98, PIL branch)."""
+    return np.asarray(Image.open(str(path)).convert("L"), dtype=np.uint8)
+
+
+# --------------------------------------------------------------------------
+# host-side silhouette preprocessing (reference :101-440, no-OpenCV branch)
+# --------------------------------------------------------------------------
+def _otsu_threshold_numpy(img: np.ndarray) -> int:
+    """Otsu level in [0, 255]; ties resolved towards the higher level
+    (reference :101-126 uses `>=`)."""
+    hist, _ = np.histogram(img.ravel(), bins=256, range=(0, 256))
+    total = img.size
+    weighted_total = np.dot(np.arange(256), hist)
+    w_back = 0.0
+    sum_back = 0.0
+    best, level = 0.0, 0
+    for i in range(256):
+        w_back += hist[i]
+        if w_back == 0:
+            continue
+        w_fore = total - w_back
+        if w_fore == 0:
+            break
+        sum_back += i * hist[i]
+        m_back = sum_back / w_back
+        m_fore = (weighted_total - sum_back) / w_fore
+        between = w_back * w_fore * (m_back - m_fore) * (m_back - m_fore)
+        if between >= best:
+            level, best = i, between
+    return int(level)
+
+
+def compute_otsu(img: np.ndarray) -> Tuple[int, np.ndarray]:
+    """(threshold, 0/255 mask): radius-1 Gaussian blur, Otsu, inversion when the
+    foreground exceeds half of the image, 3x3 closing then opening (reference
+    :129-188, branch without cv2)."""
+    try:
+        blur = np.asarray(Image.fromarray(img).filter(ImageFilter.GaussianBlur(radius=1)))
+    except Exception:
+        blur = img
+    thresh = _otsu_threshold_numpy(blur)
+    mask = (blur > thresh).astype(np.uint8) * 255
+    mask = (mask > 127).astype(np.uint8) * 255
+    if float(np.count_nonzero(mask) / mask.size) > 0.5:
+        mask = (255 - mask).astype(np.uint8)
+    if _HAS_NDIMAGE:
+        try:
+            b = mask > 127
+            b = ndi.binary_closing(b, structure=np.ones((3, 3)))
+            b = ndi.binary_opening(b, structure=np.ones((3, 3)))
+            mask = b.astype(np.uint8) * 255
+        except Exception:
+            pass
+    return int(thresh), mask.astype(np.uint8)
+
+
+def find_largest_bbox(mask: np.ndarray) -> Tuple[int, int, int, int]:
+    """x, y, w, h of the non-zero pixels; the whole image when there are none
+    (reference :191-221, branch without cv2)."""
+    h, w = mask.shape[:2]
+    coords = np.argwhere(mask > 0)
+    if coords.size == 0:
+        return 0, 0, w, h
+    y0, x0 = coords.min(axis=0)
+    y1, x1 = coords.max(axis=0)
+    return int(x0), int(y0), int(x1 - x0 + 1), int(y1 - y0 + 1)
+
+
+def pad_and_resize(img: np.ndarray, target: int, bg_color: str) -> np.ndarray:
+    """Aspect-preserving fit into target x target, centred on the background colour (reference :224-240)."""
+    fitted = ImageOps.contain(Image.fromarray(img), (target, target)).convert("L")
+    canvas = Image.new("L", (target, target), color=255 if bg_color == "white" else 0)
+    canvas.paste(fitted, ((target - fitted.width) // 2, (target - fitted.height) // 2))
+    return np.asarray(canvas, dtype=np.uint8)
+
+
+def clean_mask_np(mask_np: np.ndarray, resolution: int, min_size: Optional[int] = None) -> np.ndarray:
+    """3x3 opening, then components smaller than min_size dropped (largest kept
+    when none reaches it); default min_size = max(8, 0.1 % of resolution^2)
+    (reference :246-346, scipy.ndimage branch)."""
+    if min_size is None:
+        min_size = max(8, int(0.001 * resolution * resolution))
+    b = (mask_np > 127).astype(np.uint8)
+    if not _HAS_NDIMAGE:
+        raise RuntimeError("scipy.ndimage is required for mask cleaning")
+    b = ndi.binary_opening(b, structure=np.ones((3, 3))).astype(np.uint8)
+    labels, count = ndi.label(b)
+    if count == 0:
+        return b.astype(np.uint8) * 255
+    sizes = np.array(ndi.sum(b, labels, range(1, count + 1)))
+    keep = sizes >= min_size
+    if not keep.any():
+        keep[np.argmax(sizes)] = True
+    kept = np.isin(labels, 1 + np.nonzero(keep)[0]).astype(np.uint8)
+    return kept * 255
+
+
+def _mask_to_canvas(mask: np.ndarray, resolution: int) -> np.ndarray:
+    pil = Image.fromarray(mask).convert("L")
+    scale = min(resolution / float(pil.width), resolution / float(pil.height))
+    new_w = max(1, int(round(pil.width * scale)))
+    new_h = max(1, int(round(pil.height * scale)))
+    small = np.asarray(pil.resize((new_w, new_h), resample=Image.NEAREST), dtype=np.uint8)
+    small = clean_mask_np((small > 128).astype(np.uint8) * 255, resolution)
+    canvas = Image.new("L", (resolution, resolution), color=0)
+    canvas.paste(Image.fromarray(small).convert("L"), ((resolution - new_w) // 2, (resolution - new_h) // 2))
+    return np.asarray(canvas, dtype=np.uint8)
+
+
+def preprocess_image(img: np.ndarray, resolution: int, crop_margin: float, bg_color: str,
+                     preprocess_crop: bool) -> Tuple[np.ndarray, np.ndarray]:
+    """(preprocessed gray image, cleaned 0/255 silhouette), both
+    resolution x resolution uint8 (reference :352-440)."""
+    assert img.ndim == 2
+    h, w = img.shape[:2]
+    try:
+        _, mask = compute_otsu(img)
+    except Exception:
+        mask = (img > int(np.median(img))).astype(np.uint8) * 255
+    if not preprocess_crop:
+        return pad_and_resize(img, resolution, bg_color), _mask_to_canvas(mask, resolution)
+    x, y, ww, hh = find_largest_bbox(mask)
+    side = max(ww, hh)
+    pad = int(round(crop_margin * side)) if crop_margin <= 1.0 else int(round(crop_margin))
+    x0, y0 = max(0, x - pad), max(0, y - pad)
+    x1, y1 = min(w, x + ww + pad), min(h, y + hh + pad)
+    if x1 <= x0 or y1 <= y0:
+        x0, y0, x1, y1 = 0, 0, w, h
+    return (pad_and_resize(img[y0:y1, x0:x1], resolution, bg_color),
+            _mask_to_canvas(mask[y0:y1, x0:x1], resolution))
+
+
+# --------------------------------------------------------------------------
+# device path
+# --------------------------------------------------------------------------
+def _device():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("no HIP device visible: the Hu extractor runs on the GPU only")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def compute_hu_batch(images: Sequence[np.ndarray] | np.ndarray, thresh: int = -1, on_value: int = 255,
+                     group_sizes: Optional[Sequence[int]] = None):
+    """float32 [B, 7] log-Hu vectors of equally sized uint8 images in one
+    launch.  With group_sizes (views per sample, summing to B) also returns the
+    float32 [G, 14] mean || std table computed on the device."""
+    import torch
+    from . import engine
+
+    arr = np.ascontiguousarray(np.stack([np.asarray(i).astype(np.uint8) for i in images])
+                               if not isinstance(images, np.ndarray) else images.astype(np.uint8))
+    if arr.ndim == 2:
+        arr = arr[None]
+    dev = _device()
+    d_img = torch.from_numpy(arr).to(dev)
+    res = engine.hu_batch(d_img, thresh=thresh, on_value=on_value)
+    if group_sizes is None:
+        return res["hulog7"].cpu().numpy()
+    off = np.zeros(len(group_sizes) + 1, dtype=np.int64)
+    np.cumsum(np.asarray(group_sizes, dtype=np.int64), out=off[1:])
+    if off[-1] != arr.shape[0]:
+        raise ValueError("group_sizes must sum to the number of images")
+    stats = engine.hu_groupstat(res["hulog7"], torch.from_numpy(off).to(dev))
+    return res["hulog7"].cpu().numpy(), stats.cpu().numpy()
+
+
+def compute_hu_from_image(img_or_mask: np.ndarray) -> np.ndarray:
+    """float32 [7]: -sign(h) * log10(|h| + 1e-300) of the seven Hu invariants
+    of a grayscale image or 0/255 mask, pixel value = weight (reference :443-478)."""
+    return compute_hu_batch(np.asarray(img_or_mask).astype(np.uint8)[None])[0]
+
+
+def save_descriptor_npy(sample_id: str, vec: np.ndarray, out_dir: Path) -> Path:
+    """<id>_hu.npy, float32 (reference :481-488)."""
+    ensure_dir(out_dir)
+    p = out_dir / f"{sample_id}_hu.npy"
+    np.save(str(p), vec.astype(np.float32), allow_pickle=False)
+    return p
+
+
+def append_to_csv(records: List[Dict[str, Any]], out_csv_path: Path, overwrite: bool = False) -> None:
+    """Writes records with the fixed column order id, hu1..7_mean, hu1..7_std,
+    note; when the file exists and overwrite is False the new rows are appended
+    and the last row per id wins (reference :491-507)."""
+    import pandas as pd
+    df_new = pd.DataFrame(records, columns=HU_COLS)
+    if out_csv_path.exists() and not overwrite:
+        try:
+            both = pd.concat([pd.read_csv(out_csv_path), df_new], ignore_index=True)
+            both.drop_duplicates(subset=["id"], keep="last").to_csv(out_csv_path, index=False)
+            return
+        except Exception as e:
+            logger.debug(f"Failed to append to existing CSV; will overwrite. Error: {e}")
+    df_new.to_csv(out_csv_path, index=False)
+
+
+def _log_error(reports_dir: Path, where, kind: str, msg) -> None:
+    try:
+        ensure_dir(reports_dir)
+        with open(reports_dir / "read_errors.log", "a", encoding="utf-8") as fh:
+            fh.write(f"{where}\t{kind}\t{msg}\n")
+    except Exception:
+        pass
+
+
+def process_samples(tasks: Iterable[Tuple[str, str, Dict[str, Any]]]) -> List[Dict[str, Any]]:
+    """Batched process_sample_worker: decodes and preprocesses every view of
+    every sample on the host, sends all targets through one moment launch and
+    one group mean/std launch, writes <id>_hu.npy per sample and returns one
+    {"success", "id", "vec", "note"} dict per task in task order (reference
+    :602-667).  Views that fail to load are logged to
+    <reports_dir>/read_errors.log and skipped; a sample without usable views
+    fails with note "failed: ..."."""
+    tasks = list(tasks)
+    results: List[Dict[str, Any]] = []
+    targets: List[np.ndarray] = []
+    owners: List[int] = []
+    for k, (sample_id, dir_path_str, config) in enumerate(tasks):
+        res = {"success": False, "id": sample_id, "vec": None, "note": ""}
+        results.append(res)
+        dir_path = Path(dir_path_str)
+        reports_dir = Path(config.get("reports_dir", "reports"))
+        try:
+            view_files = list_view_files(dir_path)
+            if not view_files:
+                raise FileNotFoundError(f"No view images in {dir_path}")
+            res["_n_files"] = len(view_files)
+            for vpath in view_files:
+                try:
+                    img = load_image(vpath)
+                    preproc, mask = preprocess_image(img, int(config["resolution"]), float(config["crop_margin"]),
+                                                     config["bg_color"], bool(config["preprocess_crop"]))
+                    targets.append(mask if bool(config["use_silhouette"]) else preproc)
+                    owners.append(k)
+                except Exception as e:
+                    _log_error(reports_dir, vpath, type(e).__name__, e)
+        except Exception as e:
+            _log_error(reports_dir, dir_path, type(e).__name__, e)
+            res["note"] = f"failed: {e}"
+
+    owners_arr = np.asarray(owners, dtype=np.int64)
+    stats_by_task: Dict[int, np.ndarray] = {}
+    # one launch per distinct target shape (normally a single one: resolution^2)
+    shapes = sorted({t.shape for t in targets})
+    for shp in shapes:
+        idx = [i for i, t in enumerate(targets) if t.shape == shp]
+        own = owners_arr[idx]
+        order = np.argsort(own, kind="stable")
+        own = own[order]
+        uniq, counts = np.unique(own, return_counts=True)
+        stack = np.stack([targets[idx[i]] for i in order])
+        try:
+            _, stats = compute_hu_batch(stack, group_sizes=counts.tolist())
+            for g, k in enumerate(uniq.tolist()):
+                stats_by_task[k] = stats[g]
+        except Exception as e:
+            for k in uniq.tolist():
+                results[k]["note"] = f"failed: {e}"
+
+    for k, (sample_id, dir_path_str, config) in enumerate(tasks):
+        res = results[k]
+        n_files = res.pop("_n_files", 0)
+        if res["note"].startswith("failed"):
+            continue
+        try:
+            if k not in stats_by_task:
+                raise RuntimeError("No usable views for Hu computation")
+            vec = stats_by_task[k].astype(np.float32)
+            out_dir = Path(config["out_dir"])
+            ensure_dir(out_dir)
+            np.save(str(out_dir / f"{sample_id}_hu.npy"), vec, allow_pickle=False)
+            note = "partial_views" if n_files < int(config["expected_views"]) else "ok"
+            res.update({"success": True, "vec": vec.tolist(), "note": note})
+        except Exception as e:
+            _log_error(Path(config.get("reports_dir", "reports")), dir_path_str, type(e).__name__, e)
+            res["note"] = f"failed: {e}"
+    return results
+
+
+def process_sample_worker(args_tuple: Tuple) -> Dict[str, Any]:
+    """(sample_id, dir, config) -> {"success", "id", "vec", "note"} (reference :602-667)."""
+    return process_samples([args_tuple])[0]
+
+
+def results_to_records(results: List[Dict[str, Any]]) -> List[Dict[str, Any]]:
+    """CSV rows; failed samples get NaN features and keep their note (reference :763-785)."""
+    records = []
+    for r in results:
+        rec: Dict[str, Any] = {"id": r.get("id")}
+        if r.get("success"):
+            vec = np.asarray(r.get("vec"), dtype=np.float32)
+            vals = [float(v) for v in vec.tolist()]
+        else:
+            vals = [float("nan")] * 14
+        for i in range(7):
+            rec[f"hu{i + 1}_mean"] = vals[i]
+        for i in range(7):
+            rec[f"hu{i + 1}_std"] = vals[7 + i]
+        rec["note"] = r.get("note", "")
+        records.append(rec)
+    return records
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description="Extract Hu moments per view and aggregate per sample (MI355X)")
+    p.add_argument("--views_dir", type=str, default="../../data/processed/views/")
+    p.add_argument("--out_dir", type=str, default="../../data/processed/2d_hu")
+    p.add_argument("--resolution", type=int, default=224)
+    p.add_argument("--use_silhouette", action="store_true")
+    p.add_argument("--preprocess_crop", action="store_true")
+    p.add_argument("--crop_margin", type=float, default=0.05)
+    p.add_argument("--bg_color", type=str, default="white", choices=["white", "black"])
+    p.add_argument("--n_preview", type=int, default=0, help="accepted for compatibility; previews are not rendered")
+    p.add_argument("--workers", type=int, default=1, help="accepted for compatibility; the GPU batches instead")
+    p.add_argument("--fast", action="store_true")
+    p.add_argument("--max_samples", type=int, default=None)
+    p.add_argument("--expected_views", type=int, default=12)
+    p.add_argument("--overwrite", action="store_true")
+    p.add_argument("--reports_dir", type=str, default="../../reports")
+    p.add_argument("--batch_samples", type=int, default=512, help="samples per device batch")
+    p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--verbose", action="store_true")
+    return p.parse_args(argv)
+
+
+def main(argv=None) -> int:
+    """CLI with the reference's flags and outputs (:703-884):
+    hu_features_table.csv, <id>_hu.npy, hu_feature_stats.csv, the run config."""
+    import pandas as pd
+
+    args = parse_args(argv)
+    logging.basicConfig(level=logging.DEBUG if args.verbose else logging.INFO,
+                        format="%(asctime)s [%(levelname)s] %(message)s")
+    views_dir, out_dir, reports_dir = Path(args.views_dir), Path(args.out_dir), Path(args.reports_dir)
+    ensure_dir(reports_dir)
+    ensure_dir(out_dir)
+    ids = list_sample_ids(views_dir)
+    if not ids:
+        logger.warning(f"No sample directories found under {views_dir}")
+        return 0
+    limit = 20 if args.fast else args.max_samples
+    if limit is not None:
+        ids = ids[:limit]
+    config = {"out_dir": str(out_dir), "resolution": int(args.resolution), "use_silhouette": bool(args.use_silhouette),
+              "preprocess_crop": bool(args.preprocess_crop), "crop_margin": float(args.crop_margin),
+              "bg_color": args.bg_color, "expected_views": int(args.expected_views),
+              "overwrite": bool(args.overwrite), "reports_dir": str(reports_dir)}
+    tasks = [(sid, str(d), config) for sid, d in ids]
+    results: List[Dict[str, Any]] = []
+    step = max(1, int(args.batch_samples))
+    for i in range(0, len(tasks), step):
+        results.extend(process_samples(tasks[i:i + step]))
+    out_csv = out_dir / "hu_features_table.csv"
+    append_to_csv(results_to_records(results), out_csv, overwrite=args.overwrite)
+    try:
+        num = pd.read_csv(out_csv).select_dtypes(include=[np.number])
+        num.agg(["mean", "std"]).transpose().reset_index().rename(columns={"index": "feature"}).to_csv(
+            reports_dir / "hu_feature_stats.csv", index=False)
+    except Exception as e:
+        logger.debug(f"Failed to write hu_feature_stats.csv: {e}")
+    cfg = dict(config, timestamp=datetime.datetime.now().isoformat(sep=" ", timespec="seconds"),
+               views_dir=str(views_dir), workers=int(args.workers), seed=int(args.seed))
+    try:
+        import yaml
+        with open(out_dir / "extract_2d_hu_config.yaml", "w", encoding="utf-8") as fh:
+            yaml.safe_dump(cfg, fh)
+    except Exception:
+        logger.debug("Failed to write config YAML")
+    mode = "fast" if args.fast else "full"
+    print(f"Hu extraction finished. Mode: {mode}. Samples processed: {len(results)}. Descriptors saved to {out_dir}.")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))

@@ -1,0 +1,271 @@
+"""PCA descriptor extraction on MI355X behind the reference's function names.
+
+Mirrors reference src/features/extract_3d_pca_features.py: the same function
+names, argument meaning, return shapes, record/CSV layout and error behaviour;
+the arithmetic of compute_pca_features (:59-145) runs in the HIP kernels of
+libfx (csrc/fx_pca.hip).  There is no CPU fallback.
+
+Differences from the reference that a caller can observe:
+  * `compute_pca_features_batch` / `process_files` exist in addition: they put
+    many sets through one kernel launch (the reference has only the per-file
+    functions and a multiprocessing pool around them);
+  * inputs are evaluated from their float32 values (the reference's
+    load_sample widens float32 files to float64, which is exact, so file inputs
+    behave identically; float64 arrays handed to compute_pca_features directly
+    are rounded to float32 first).
+"""
+from __future__ import annotations
+
+import argparse
+import logging
+import sys
+from pathlib import Path
+from typing import Iterable, List, Optional, Sequence
+
+import numpy as np
+
+logger = logging.getLogger("pca_features")
+
+BASE_COLS = ["id", "raw_path", "n_points", "lambda1", "lambda2", "lambda3",
+             "r1", "r2", "r3", "ratio12", "ratio23", "trace"]
+
+
+def column_names(n_bins: int) -> List[str]:
+    """CSV header of descriptors_table_pca.csv (reference :383-386)."""
+    return BASE_COLS + [f"proj_hist_bin_{i}" for i in range(n_bins)]
+
+
+def ensure_dir(p: Path) -> None:
+    p.mkdir(parents=True, exist_ok=True)
+
+
+def load_sample(path: Path) -> np.ndarray:
+    """Nx3 float64 array from a sampled .npy file; ValueError on a bad shape
+    (reference :48-56)."""
+    arr = np.load(path, allow_pickle=False)
+    if arr.ndim != 2 or arr.shape[1] < 3:
+        raise ValueError(f"invalid shape {arr.shape} (expected Nx3) for {path}")
+    return arr[:, :3].astype(np.float64)
+
+
+def _device():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("no HIP device visible: the PCA extractor runs on the GPU only")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def compute_pca_features_batch(point_sets: Sequence[np.ndarray], n_bins: int = 8, normalize: bool = False,
+                               return_eig: bool = False):
+    """Descriptors of many point sets in one launch -> float32 [B, 9+n_bins].
+    Sets may differ in size; a set with fewer than 3 points raises ValueError
+    like the per-set function."""
+    import torch
+    from . import engine
+
+    sets = [np.asarray(p) for p in point_sets]
+    for p in sets:
+        if p.ndim != 2 or p.shape[1] < 2:
+            raise ValueError(f"invalid shape {p.shape} (expected Nx3)")
+        if p.shape[0] < 3:
+            raise ValueError("too few points (<3)")
+    dev = _device()
+    if not sets:
+        empty = np.zeros((0, 9 + n_bins), dtype=np.float32)
+        return (empty, np.zeros((0, 6))) if return_eig else empty
+    dims = 3 if sets[0].shape[1] >= 3 else 2
+    sizes = np.array([p.shape[0] for p in sets], dtype=np.int64)
+    flat = np.concatenate([np.ascontiguousarray(p[:, :dims], dtype=np.float32) for p in sets], axis=0)
+    d_pts = torch.from_numpy(flat).to(dev)
+    if np.all(sizes == sizes[0]):
+        res = engine.pca_batch(d_pts.view(len(sets), int(sizes[0]), dims), None, n_bins, normalize, eig=return_eig)
+    else:
+        off = np.zeros(len(sets) + 1, dtype=np.int64)
+        np.cumsum(sizes, out=off[1:])
+        res = engine.pca_batch(d_pts, torch.from_numpy(off).to(dev), n_bins, normalize, eig=return_eig)
+    out = res["out"].cpu().numpy()
+    return (out, res["eig"].cpu().numpy()) if return_eig else out
+
+
+def compute_pca_features(points: np.ndarray, n_bins: int = 8, normalize: bool = False) -> np.ndarray:
+    """float32 [9 + n_bins]: lambda1..3, r1..3, ratio12, ratio23, trace,
+    |projection on PC1| histogram (reference :59-145)."""
+    if points.shape[0] < 3:
+        raise ValueError("too few points (<3)")
+    return compute_pca_features_batch([points], n_bins=n_bins, normalize=normalize)[0]
+
+
+def save_descriptor(sample_id: str, vec: np.ndarray, out_dir: Path) -> Path:
+    """pca_<id>.npy, float32 (reference :148-157)."""
+    ensure_dir(out_dir)
+    out_path = out_dir / f"pca_{sample_id}.npy"
+    np.save(str(out_path), vec.astype(np.float32), allow_pickle=False)
+    return out_path
+
+
+def build_manifest_map(manifest_path: Path) -> dict:
+    """id -> raw_path from a manifest CSV with those two columns (reference :164-174)."""
+    import pandas as pd
+    mapping = {}
+    if manifest_path.exists():
+        try:
+            df = pd.read_csv(manifest_path)
+            if "id" in df.columns and "raw_path" in df.columns:
+                mapping = {str(i): str(r) for i, r in zip(df["id"], df["raw_path"])}
+        except Exception as e:  # unreadable manifest is not fatal in the reference either
+            logger.warning(f"Could not read manifest {manifest_path}: {e}")
+    return mapping
+
+
+def _blank_record(file_path: Path, manifest_map: dict) -> dict:
+    return {"id": file_path.stem, "raw_path": manifest_map.get(file_path.stem, ""), "n_points": None,
+            "lambda1": None, "lambda2": None, "lambda3": None, "r1": None, "r2": None, "r3": None,
+            "ratio12": None, "ratio23": None, "trace": None, "proj_hist": None, "descriptor_path": ""}
+
+
+def _log_error(reports_dir: Path, file_path: Path, e: Exception) -> None:
+    try:
+        ensure_dir(Path(reports_dir))
+        with open(Path(reports_dir) / "read_errors.log", "a", encoding="utf-8") as fh:
+            fh.write(f"{file_path}\t{type(e).__name__}\t{e}\n")
+    except Exception:
+        pass
+
+
+def _fill_record(record: dict, n_pts: int, vec: np.ndarray, desc_path: Path) -> None:
+    vals = vec[:9].astype(float).tolist()
+    record.update(dict(zip(["lambda1", "lambda2", "lambda3", "r1", "r2", "r3", "ratio12", "ratio23", "trace"], vals)))
+    record["n_points"] = n_pts
+    record["proj_hist"] = vec[9:].astype(float).tolist()
+    record["descriptor_path"] = str(desc_path.resolve())
+
+
+def process_files(tasks: Iterable[tuple]) -> List[dict]:
+    """Batched process_file: loads every file on the host, runs one kernel
+    launch over all loadable sets, saves pca_<id>.npy per set and returns one
+    result dict per task, in task order, with the reference's layout
+    ({"success", "record", "error"}, :194-262)."""
+    tasks = list(tasks)
+    results: List[Optional[dict]] = [None] * len(tasks)
+    loaded = []
+    for k, t in enumerate(tasks):
+        (file_path_str, _sampled, out_dir_str, n_bins, normalize, _overwrite, manifest_map, reports_dir_str) = t
+        file_path = Path(file_path_str)
+        manifest_map = manifest_map if isinstance(manifest_map, dict) else {}
+        record = _blank_record(file_path, manifest_map)
+        try:
+            pts = load_sample(file_path)
+            if int(pts.shape[0]) < 3:
+                raise ValueError("too few points (<3) after loading")
+            loaded.append((k, pts, record, Path(out_dir_str), int(n_bins), bool(normalize)))
+        except Exception as e:
+            _log_error(Path(reports_dir_str), file_path, e)
+            results[k] = {"success": False, "record": record, "error": str(e)}
+    # one launch per (n_bins, normalize) combination present
+    groups = {}
+    for item in loaded:
+        groups.setdefault((item[4], item[5]), []).append(item)
+    for (n_bins, normalize), items in groups.items():
+        try:
+            vecs = compute_pca_features_batch([it[1] for it in items], n_bins=n_bins, normalize=normalize)
+            err = None
+        except Exception as e:
+            vecs, err = None, e
+        for j, (k, pts, record, out_dir, _nb, _nz) in enumerate(items):
+            file_path = Path(tasks[k][0])
+            try:
+                if err is not None:
+                    raise err
+                desc_path = save_descriptor(file_path.stem, vecs[j], out_dir)
+                _fill_record(record, int(pts.shape[0]), vecs[j], desc_path)
+                results[k] = {"success": True, "record": record, "error": ""}
+            except Exception as e:
+                _log_error(Path(tasks[k][7]), file_path, e)
+                results[k] = {"success": False, "record": record, "error": str(e)}
+    return results  # type: ignore[return-value]
+
+
+def process_file(args_tuple):
+    """One file -> {"success", "record", "error"} (reference :194-262)."""
+    return process_files([args_tuple])[0]
+
+
+def records_to_frame(records: List[dict], n_bins: int):
+    """DataFrame with the exact column order of descriptors_table_pca.csv
+    (reference :383-414)."""
+    import pandas as pd
+    rows = []
+    for rec in records:
+        row = {c: rec.get(c, np.nan) for c in BASE_COLS}
+        row["id"] = rec.get("id", "")
+        row["raw_path"] = rec.get("raw_path", "")
+        hist = rec.get("proj_hist") or [0.0] * n_bins
+        hist = list(hist) + [0.0] * max(0, n_bins - len(hist))
+        for i in range(n_bins):
+            row[f"proj_hist_bin_{i}"] = float(hist[i])
+        rows.append(row)
+    return pd.DataFrame(rows, columns=column_names(n_bins))
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description="Extract PCA-based 3D descriptors from sampled point clouds (MI355X).")
+    p.add_argument("--sampled_dir", type=str, default="../../data/processed/sampled")
+    p.add_argument("--out_dir", type=str, default="../../data/processed/descriptors")
+    p.add_argument("--n_bins", type=int, default=8)
+    p.add_argument("--max_samples", type=int, default=None)
+    p.add_argument("--fast", action="store_true", help="process the first 20 files only")
+    p.add_argument("--normalize", action="store_true")
+    p.add_argument("--workers", type=int, default=1, help="accepted for compatibility; the GPU batches instead")
+    p.add_argument("--overwrite", action="store_true")
+    p.add_argument("--processed_manifest", type=str, default="")
+    p.add_argument("--reports_dir", type=str, default="../../reports")
+    p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--verbose", action="store_true")
+    return p.parse_args(argv)
+
+
+def main(argv=None) -> int:
+    """CLI with the reference's flags, outputs and exit codes (:288-449):
+    0 = ok / nothing to do, 2 = sampled_dir missing, 3 = every file failed."""
+    args = parse_args(argv)
+    logging.basicConfig(level=logging.DEBUG if args.verbose else logging.INFO,
+                        format="%(asctime)s [%(levelname)s] %(message)s")
+    sampled_dir, out_dir, reports_dir = Path(args.sampled_dir), Path(args.out_dir), Path(args.reports_dir)
+    ensure_dir(out_dir)
+    ensure_dir(reports_dir)
+    manifest_map = {}
+    if args.processed_manifest:
+        if Path(args.processed_manifest).exists():
+            manifest_map = build_manifest_map(Path(args.processed_manifest))
+    elif (sampled_dir.parent / "manifest.csv").exists():
+        manifest_map = build_manifest_map(sampled_dir.parent / "manifest.csv")
+    if not sampled_dir.exists():
+        logger.error(f"Sampled directory not found: {sampled_dir}")
+        return 2
+    files = sorted((p for p in sampled_dir.rglob("*.npy") if p.is_file()), key=lambda p: str(p))
+    limit = 20 if args.fast else args.max_samples
+    if limit is not None:
+        files = files[:limit]
+    if not files:
+        logger.warning("No .npy files found; exiting.")
+        return 0
+    tasks = [(str(p), str(sampled_dir), str(out_dir), int(args.n_bins), bool(args.normalize), bool(args.overwrite),
+              manifest_map, str(reports_dir)) for p in files]
+    results = process_files(tasks)
+    records = [r["record"] for r in results if r.get("success")]
+    if not records:
+        logger.error("No descriptors produced (all files failed). Check reports/read_errors.log for details.")
+        return 3
+    df = records_to_frame(records, int(args.n_bins))
+    df.to_csv(out_dir / "descriptors_table_pca.csv", index=False)
+    stats = df.select_dtypes(include=[np.number]).agg(["mean", "std"]).transpose().reset_index()
+    stats.rename(columns={"index": "feature"}, inplace=True)
+    stats.to_csv(reports_dir / "pca_feature_stats.csv", index=False)
+    mode = "fast" if args.fast else "full"
+    print(f"PCA descriptor extraction finished. Mode: {mode}. Samples processed: {len(records)}. "
+          f"Descriptors saved to {out_dir}.")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))

@@ -1,0 +1,159 @@
+/*
+ * fx.h -- C ABI of libfx.so, the MI355X (gfx950) Hu-moment / PCA feature engine.
+ *
+ * The reference (mohammedazan/Image-Processing) is pure Python and has no FFI
+ * of its own; the boundary it offers for this path is the function layer of
+ * src/features/extract_2d_hu.py and src/features/extract_3d_pca_features.py.
+ * Each entry point below names the reference function whose arithmetic it
+ * replaces.  A Python host binds these with ctypes and keeps the reference
+ * signatures above them.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative FX_E* code; the text of
+ *     the last failure on the calling thread is fx_last_error();
+ *   - all d_* pointers are caller-owned device pointers on the device given to
+ *     fx_init (or the current HIP device); the library never frees or keeps
+ *     them; optional outputs may be NULL;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the
+ *     default stream) and the call returns without waiting for it;
+ *   - no C++ exception crosses this boundary;
+ *   - scratch memory that an entry point needs beyond its arguments is owned
+ *     by the library, per device, and released by fx_shutdown.
+ */
+#ifndef FX_H
+#define FX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FX_OK 0
+#define FX_EINVAL (-22)   /* bad argument (shape, alignment, NULL output)    */
+#define FX_ENOMEM (-12)   /* device scratch allocation failed                */
+#define FX_EHIP (-5)      /* a HIP runtime call or kernel launch failed      */
+#define FX_ENODEV (-19)   /* no usable gfx950 device                         */
+
+/* Number of doubles per image in the moment record:
+ * m00 m10 m01 m20 m11 m02 m30 m21 m12 m03, mu20 mu11 mu02 mu30 mu21 mu12 mu03,
+ * nu20 nu11 nu02 nu30 nu21 nu12 nu03 -- the fields of cv2.moments(). */
+#define FX_MOMENTS_PER_IMAGE 24
+
+/* Selects `device` for the calling thread and creates the per-device state.
+ * Counterpart of importing cv2/NumPy in the reference scripts; there is no
+ * reference function.  Safe to call more than once. */
+int fx_init(int device);
+
+/* Releases every per-device scratch buffer the library holds. */
+int fx_shutdown(void);
+
+/* Message of the most recent failing call on this thread ("" if none). */
+const char *fx_last_error(void);
+
+/* ABI revision of this header. */
+int fx_abi_version(void);
+
+/*
+ * Batched compute_hu_from_image (reference src/features/extract_2d_hu.py:443-478:
+ * cv2.moments :449, cv2.HuMoments :450, -sign(h)*log10(|h|+1e-300) :471-478),
+ * with the binarisation that precedes it on the silhouette path fused in
+ * (`(mask > 127).astype(np.uint8) * 255`, extract_2d_hu.py:163,258,386,429).
+ *
+ *   d_img            B images of H x W uint8; row r of image b starts at
+ *                    d_img + b*img_stride_bytes + r*pitch_bytes
+ *   thresh           < 0: the pixel value is the weight (cv2.moments on a gray
+ *                    image); 0..254: pixels > thresh weigh on_value, others 0
+ *   on_value         1..255, used only when thresh >= 0
+ *   d_moments24      optional, B x 24 doubles (cv2.moments record)
+ *   d_hu7            optional, B x 7 doubles  (cv2.HuMoments, before the log)
+ *   d_hulog7         optional, B x 7 floats   (the function's return value)
+ *   n_bins, d_cpca   optional contour descriptor: when d_cpca != NULL, writes
+ *                    B x (9+n_bins) floats = compute_pca_features
+ *                    (extract_3d_pca_features.py:59-145) of the contour pixels
+ *                    (foreground pixels, v > thresh or v > 127 when thresh < 0,
+ *                    having a 4-neighbour that is background or outside the
+ *                    image) taken as points (x, y, 0).  Rows of images with
+ *                    fewer than 3 contour pixels are NaN (the reference
+ *                    function raises ValueError there).  1 <= n_bins <= 64.
+ *   d_ceig           optional with d_cpca: B x 6 doubles (lambda1..3, v1) in
+ *                    float64 before the float32 cast.
+ *
+ * Raw moments are exact integers (the value cv2.moments accumulates), the
+ * finalisation runs in IEEE double in OpenCV's operation order without FMA.
+ * Limits: 1 <= W, H <= 16384.
+ */
+int fx_hu_batch_u8(const uint8_t *d_img, int64_t B, int H, int W,
+                   int64_t pitch_bytes, int64_t img_stride_bytes,
+                   int thresh, int on_value,
+                   double *d_moments24, double *d_hu7, float *d_hulog7,
+                   int n_bins, float *d_cpca, double *d_ceig,
+                   void *stream);
+
+/*
+ * Per-sample aggregation of the per-view rows (reference
+ * src/features/extract_2d_hu.py:641-644: np.mean / np.std(ddof=0) over the
+ * stacked float32 rows, concatenated to float32[14]), in NumPy's float32
+ * evaluation order.  Rows of group g are d_hulog7[7*d_group_offsets[g]] ..
+ * d_hulog7[7*d_group_offsets[g+1]-1]; d_group_offsets has G+1 entries on the
+ * device.  d_out14 is G x 14 floats (mean[7] || std[7]); an empty group is NaN.
+ */
+int fx_hu_groupstat(const float *d_hulog7, const int64_t *d_group_offsets,
+                    int64_t G, float *d_out14, void *stream);
+
+/*
+ * Batched compute_pca_features (reference
+ * src/features/extract_3d_pca_features.py:59-145; the float32 file contents
+ * are widened to float64 in-kernel as load_sample does at :48-56).
+ *
+ *   d_pts       points, `dims` floats each (2 or 3; z = 0 when dims == 2)
+ *   d_offsets   NULL: B sets of exactly N points, set b at point b*N;
+ *               else B+1 point offsets on the device (CSR), N ignored
+ *   n_bins      1..64 bins of the |projection on PC1| histogram
+ *   normalize   != 0: divide centred points by their largest norm (:79-83)
+ *   d_out       B x (9+n_bins) floats: lambda1..3, r1..3, ratio12, ratio23,
+ *               trace, histogram.  Sets with fewer than 3 points give a NaN
+ *               row (the reference function raises ValueError, :72-73).
+ *   d_eig       optional, B x 6 doubles (lambda1..3, v1) before the cast.
+ *
+ * With d_offsets != NULL the call copies the offsets to the host and waits
+ * for `stream` once before launching.
+ */
+int fx_pca_batch_f32(const float *d_pts, const int64_t *d_offsets, int64_t B,
+                     int64_t N, int dims, int n_bins, int normalize,
+                     float *d_out, double *d_eig, void *stream);
+
+/*
+ * Synthetic inputs for benchmarks and parity tests (no reference counterpart:
+ * the reference reads rendered PNG views and sampled .npy clouds from disk).
+ * Image `first_index + b` / set `first_index + b` depends only on (seed, that
+ * index, the shape arguments), so any shard of a data set can be generated on
+ * any rank.
+ *
+ * fx_synth_shapes_u8: H x W uint8 images with values {0, 255}; the foreground
+ * is the union of 3..6 rotated ellipses and one 5..8-vertex polygon, rasterised
+ * in integer arithmetic (an identical host generator exists for tests).
+ * fx_synth_points_f32: N x 3 float32 Gaussian clouds, per-axis scale
+ * log-uniform in [0.05, 1], random rotation.
+ */
+int fx_synth_shapes_u8(uint8_t *d_img, int64_t B, int H, int W,
+                       int64_t pitch_bytes, int64_t img_stride_bytes,
+                       uint64_t seed, int64_t first_index, void *stream);
+int fx_synth_points_f32(float *d_pts, int64_t B, int64_t N, uint64_t seed,
+                        int64_t first_index, void *stream);
+
+/*
+ * Timing helper for callers that launch on a raw HIP stream: average duration
+ * in milliseconds of the kernels enqueued by the most recent fx_hu_batch_u8 /
+ * fx_pca_batch_f32 call when profiling is switched on (fx_profile(1)): the
+ * library then brackets that call's launches with HIP events on `stream`.
+ * fx_profile_last_ms waits for the events.  Returns < 0 when nothing was
+ * recorded.
+ */
+int fx_profile(int enable);
+double fx_profile_last_ms(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FX_H */

@@ -1,0 +1,40 @@
+"""Worker functions of bench.py's cpu_baseline leg (TEST/BENCH INFRASTRUCTURE:
+the CPU oracle timed on the host cores; never part of the product path).
+
+Each worker processes its slice of the sample one unit at a time, the way the
+reference's pool workers process one file at a time
+(extract_2d_hu.py:751-752, extract_3d_pca_features.py:349-350).
+"""
+import time
+
+import numpy as np
+
+from oracle import cpu_ref
+
+
+def warm(job):
+    """Imports, builds/loads the C oracle and maps the sample; untimed."""
+    cpu_ref.load_c_oracle()
+    np.load(job[1], mmap_mode="r")
+    return True
+
+
+def run(job):
+    kind, path, lo, hi = job
+    data = np.load(path, mmap_mode="r")[lo:hi]
+    data = np.ascontiguousarray(data)
+    c = cpu_ref.load_c_oracle()
+    t0 = time.perf_counter()
+    if kind == "pca":
+        for pts in data:
+            cpu_ref.compute_pca_features(pts.astype(np.float64), 8, False)
+    elif kind == "hu":
+        for img in data:
+            c.hu_batch(img[None], thresh=127, on_value=255)
+    else:
+        for img in data:
+            c.hu_batch(img[None], thresh=127, on_value=255)
+            pts = c.contour_points(img, 127)
+            if pts.shape[0] >= 3:
+                cpu_ref.compute_pca_features(pts, 8, False)
+    return hi - lo, time.perf_counter() - t0

@@ -1,0 +1,156 @@
+"""Parity of the HIP Hu path (through the C ABI) with the CPU oracle."""
+import numpy as np
+import pytest
+
+from conftest import pkg
+
+pytestmark = pytest.mark.gpu
+
+LOG_RTOL = 1e-5  # relative tolerance on log-scaled Hu in float64 before the float32 cast
+
+
+def run_gpu(gpu, imgs, thresh=-1, on_value=255, **kw):
+    import torch
+    eng = pkg("engine")
+    t = torch.from_numpy(np.ascontiguousarray(imgs)).to(gpu)
+    res = eng.hu_batch(t, thresh=thresh, on_value=on_value, moments=True, hu=True, **kw)
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in res.items()}
+
+
+def check_against_oracle(got, ref):
+    # raw moments are integers: bit-exact; central/normalised moments and the
+    # invariants follow the same IEEE operation order: bit-exact too
+    np.testing.assert_array_equal(got["moments24"][:, :10], ref["moments24"][:, :10])
+    np.testing.assert_array_equal(got["moments24"], ref["moments24"])
+    np.testing.assert_array_equal(got["hu7"], ref["hu7"])
+    # log10 comes from different math libraries: relative 1e-5 in float64 terms,
+    # and at most 1 float32 ulp after the cast
+    a, b = got["hulog7"].astype(np.float64), ref["hulog7_f64"]
+    assert np.all(np.abs(a - b) <= LOG_RTOL * np.abs(b) + 1e-30)
+    ulp = np.spacing(np.abs(ref["hulog7"]).astype(np.float32))
+    assert np.all(np.abs(got["hulog7"] - ref["hulog7"]) <= ulp)
+
+
+@pytest.mark.parametrize("size", [(224, 224), (256, 256), (512, 512), (64, 1024), (300, 200), (17, 33), (1, 1), (5, 2048), (2048, 16)])
+def test_shapes_binary_default(gpu, c_oracle, size):
+    H, W = size
+    B = 6
+    synth = pkg("synth")
+    if H >= 8 and W >= 8:
+        imgs = synth.shapes_host(B, H, W, seed=7)
+    else:
+        imgs = (np.random.default_rng(1).integers(0, 2, size=(B, H, W)) * 255).astype(np.uint8)
+    check_against_oracle(run_gpu(gpu, imgs), c_oracle.hu_batch(imgs))
+    check_against_oracle(run_gpu(gpu, imgs, thresh=127), c_oracle.hu_batch(imgs, thresh=127))
+
+
+@pytest.mark.parametrize("thresh,on", [(-1, 255), (127, 255), (128, 255), (0, 1), (200, 77), (254, 255)])
+def test_gray_images_and_thresholds(gpu, c_oracle, thresh, on):
+    rng = np.random.default_rng(3)
+    imgs = rng.integers(0, 256, size=(5, 96, 144), dtype=np.uint8)
+    imgs[0] = 0          # empty image: m00 = 0 -> all outputs 0
+    imgs[1] = 255        # full image
+    imgs[2, :, :] = 0
+    imgs[2, 40, 70] = 255  # single pixel
+    check_against_oracle(run_gpu(gpu, imgs, thresh, on), c_oracle.hu_batch(imgs, thresh, on))
+
+
+def test_reference_silhouette_panels(gpu, c_oracle, hu_panels):
+    """The 21 cleaned silhouettes the reference's production run computed Hu on."""
+    check_against_oracle(run_gpu(gpu, hu_panels["masks"]), c_oracle.hu_batch(hu_panels["masks"]))
+    check_against_oracle(run_gpu(gpu, hu_panels["preproc"]), c_oracle.hu_batch(hu_panels["preproc"]))
+
+
+def test_padded_rows_and_unaligned_base(gpu, c_oracle):
+    import torch
+    eng = pkg("engine")
+    imgs = pkg("synth").shapes_host(4, 100, 100, seed=11)
+    ref = c_oracle.hu_batch(imgs)
+    big = torch.zeros((4, 104, 131), dtype=torch.uint8, device=gpu)
+    view = big[:, 3:103, 5:105]
+    view.copy_(torch.from_numpy(imgs).to(gpu))
+    res = eng.hu_batch(view, moments=True, hu=True)
+    got = {k: v.cpu().numpy() for k, v in res.items()}
+    check_against_oracle(got, ref)
+
+
+def test_compute_hu_from_image_signature(gpu, c_oracle, hu_panels):
+    mod = pkg("extract_2d_hu")
+    out = mod.compute_hu_from_image(hu_panels["masks"][0])
+    assert out.dtype == np.float32 and out.shape == (7,)
+    ref = c_oracle.hu_batch(hu_panels["masks"][:1])["hulog7"][0]
+    assert np.all(np.abs(out - ref) <= np.spacing(np.abs(ref)))
+
+
+def test_groupstat(gpu, oracle, c_oracle):
+    import torch
+    eng = pkg("engine")
+    rng = np.random.default_rng(5)
+    rows = (rng.normal(size=(57, 7)) * np.array([0.1, 0.3, 0.5, 1, 10, 5, 20]) + np.array([3, 6, 9, 10, 15, 10, 0])).astype(np.float32)
+    off = np.array([0, 12, 24, 25, 25, 45, 57], dtype=np.int64)
+    got = eng.hu_groupstat(torch.from_numpy(rows).to(gpu), torch.from_numpy(off).to(gpu)).cpu().numpy()
+    ref_np = oracle.hu_groupstat(rows, off.tolist())
+    ref_c = c_oracle.hu_groupstat(rows, off)
+    np.testing.assert_array_equal(ref_c, ref_np)  # the two restatements agree bit for bit
+    np.testing.assert_array_equal(got, ref_np)    # so does the kernel (NaN rows for the empty group included)
+
+
+def test_device_generator_matches_host_twin(gpu):
+    eng, synth = pkg("engine"), pkg("synth")
+    for (B, H, W, first) in [(5, 256, 256, 0), (3, 512, 512, 1000), (2, 224, 224, 7), (2, 100, 260, 3)]:
+        dev = eng.synth_shapes(B, H, W, seed=42, first_index=first, device=gpu).cpu().numpy()
+        np.testing.assert_array_equal(dev, synth.shapes_host(B, H, W, seed=42, first_index=first))
+
+
+@pytest.mark.parametrize("size,nb", [((256, 256), 8), ((512, 512), 8), ((224, 224), 5), ((100, 260), 16), ((40, 1000), 8)])
+def test_contour_descriptor(gpu, oracle, size, nb):
+    H, W = size
+    imgs = pkg("synth").shapes_host(6, H, W, seed=21)
+    imgs[5] = 0
+    imgs[5, 10, 10:12] = 255  # two contour pixels only -> NaN row
+    got = run_gpu(gpu, imgs, contour_bins=nb, contour_eig=True)
+    ties = 0
+    for b in range(imgs.shape[0]):
+        ref, eig = oracle.contour_pca_features(imgs[b], 127, nb, return_eig=True)
+        if np.isnan(ref).all():
+            assert np.isnan(got["cpca"][b]).all()
+            continue
+        lam, lam_ref = got["ceig"][b, :3], eig[:3]
+        assert np.all(np.abs(lam - lam_ref) <= 1e-9 * lam_ref[0])          # eigenvalues, float64
+        assert abs(abs(np.dot(got["ceig"][b, 3:], eig[3:])) - 1.0) <= 1e-9  # v1 up to sign
+        np.testing.assert_allclose(got["cpca"][b, :9], ref[:9], rtol=1e-6, atol=1e-30)
+        n = oracle.contour_points(imgs[b]).shape[0]
+        dcount = np.abs(got["cpca"][b, 9:].astype(np.float64) - ref[9:]) * n
+        ties += int(np.round(dcount.sum() / 2))
+        assert dcount.max() <= 2.5, "histogram differs by more than edge ties"
+    assert ties <= 2
+
+
+def test_full_size_properties(gpu):
+    """C2/C3-sized batches: properties that need no CPU pass over the data.
+    Raw moments are additive over disjoint masks and the Hu vector is invariant
+    under translation of the shape."""
+    import torch
+    eng = pkg("engine")
+    B, H, W = 2048, 512, 512
+    imgs = eng.synth_shapes(B, H, W, seed=42, device=gpu)
+    res = eng.hu_batch(imgs, moments=True, hu=True)
+    left, right = imgs.clone(), imgs.clone()
+    left[:, :, W // 2:] = 0
+    right[:, :, : W // 2] = 0
+    ml = eng.hu_batch(left, moments=True)["moments24"][:, :10]
+    mr = eng.hu_batch(right, moments=True)["moments24"][:, :10]
+    assert torch.equal(ml + mr, res["moments24"][:, :10])
+    # m00 = 255 * foreground pixel count
+    assert torch.equal(res["moments24"][:, 0], 255.0 * (imgs > 127).sum(dim=(1, 2)).double())
+    # translation by (dx, dy) inside the canvas: shapes live in the central half
+    small = eng.synth_shapes(64, 256, 256, seed=5, device=gpu)
+    canvas_a = torch.zeros((64, 512, 512), dtype=torch.uint8, device=gpu)
+    canvas_b = torch.zeros_like(canvas_a)
+    canvas_a[:, 10:266, 20:276] = small
+    canvas_b[:, 200:456, 150:406] = small
+    ha = eng.hu_batch(canvas_a, hu=True)["hu7"]
+    hb = eng.hu_batch(canvas_b, hu=True)["hu7"]
+    scale = ha.abs().max(dim=0).values
+    assert torch.all((ha - hb).abs() <= 1e-6 * ha.abs() + 1e-7 * scale)

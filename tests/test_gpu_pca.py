@@ -1,0 +1,121 @@
+"""Parity of the HIP point-set PCA path (through the C ABI) with the CPU oracle."""
+import numpy as np
+import pytest
+
+from conftest import pkg
+
+pytestmark = pytest.mark.gpu
+
+EIG_RTOL = 1e-9    # eigenvalues in float64, relative to lambda1 (and per value where well conditioned)
+OUT_RTOL = 1e-6    # the nine scalars after the float32 cast
+
+
+def compare_set(got_out, got_eig, ref_out, ref_eig, n, strict_rel=True):
+    """Returns the number of histogram counts that moved across a bin edge."""
+    lam, lam_ref = got_eig[:3], ref_eig[:3]
+    assert np.all(np.abs(lam - lam_ref) <= EIG_RTOL * max(lam_ref[0], 1e-300))
+    if strict_rel:
+        # per-value relative bound wherever the value is not itself at rounding level
+        big = lam_ref >= 1e-4 * lam_ref[0]
+        assert np.all(np.abs(lam - lam_ref)[big] <= EIG_RTOL * np.abs(lam_ref)[big])
+    gap = lam_ref[0] - lam_ref[1]
+    if gap > 1e-6 * lam_ref[0]:
+        assert abs(abs(np.dot(got_eig[3:], ref_eig[3:])) - 1.0) <= 1e-9
+    # after the float32 cast: relative 1e-6, plus an absolute floor for values that
+    # are rounding noise themselves (lambda3, r3 of rank-deficient sets)
+    l1 = max(float(lam_ref[0]), 1e-300)
+    atol = np.array([l1, l1, l1, 1.0, 1.0, 1.0, 0.0, 0.0, l1]) * 1e-9
+    assert np.all(np.abs(got_out[:9].astype(np.float64) - ref_out[:9]) <= OUT_RTOL * np.abs(ref_out[:9]) + atol)
+    moved = np.abs(got_out[9:].astype(np.float64) - ref_out[9:].astype(np.float64)) * n
+    assert moved.max() <= 2.5, "histogram differs by more than edge ties"
+    return int(np.round(moved.sum() / 2))
+
+
+def test_reference_golden_vectors(gpu, oracle, pca_golden):
+    """Outputs of the reference's own compute_pca_features (tests/golden/pca_golden.npz)."""
+    mod = pkg("extract_3d_pca_features")
+    ties = 0
+    for case in pca_golden:
+        pts = case["pts"]
+        assert np.array_equal(pts.astype(np.float32).astype(np.float64), pts)
+        out, eig = mod.compute_pca_features_batch([pts], case["n_bins"], case["normalize"], return_eig=True)
+        ref_out, ref_eig = oracle.compute_pca_features(pts, case["n_bins"], case["normalize"], return_eig=True)
+        np.testing.assert_array_equal(ref_out, case["out"])  # oracle == reference output
+        degenerate = ref_eig[2] <= 1e-9 * max(ref_eig[0], 1e-300)
+        ties += compare_set(out[0], eig[0], case["out"], ref_eig, pts.shape[0], strict_rel=not degenerate)
+        if ref_eig[2] == 0.0:
+            assert eig[0][2] == 0.0  # planar / collinear sets: exact zero like LAPACK
+    assert ties <= 1
+
+
+def test_single_set_signature_and_errors(gpu, oracle):
+    mod = pkg("extract_3d_pca_features")
+    pts = pkg("synth").points_host(1, 1024, seed=3)[0].astype(np.float64)
+    out = mod.compute_pca_features(pts, n_bins=8, normalize=False)
+    assert out.dtype == np.float32 and out.shape == (17,)
+    np.testing.assert_allclose(out[:9], oracle.compute_pca_features(pts)[:9], rtol=OUT_RTOL)
+    with pytest.raises(ValueError, match=r"too few points \(<3\)"):
+        mod.compute_pca_features(np.zeros((2, 3)))
+
+
+@pytest.mark.parametrize("N,normalize,nb", [(1024, False, 8), (1024, True, 8), (1000, False, 8), (65, False, 4),
+                                            (2048, False, 8), (3000, False, 8), (20000, True, 16)])
+def test_device_clouds_vs_oracle(gpu, oracle, N, normalize, nb):
+    import torch
+    eng = pkg("engine")
+    B = 24 if N <= 4096 else 4
+    pts = eng.synth_points(B, N, seed=42, first_index=5, device=gpu)
+    res = eng.pca_batch(pts, None, nb, normalize, eig=True)
+    torch.cuda.synchronize()
+    host = pts.cpu().numpy().astype(np.float64)
+    out, eig = res["out"].cpu().numpy(), res["eig"].cpu().numpy()
+    ties = 0
+    for b in range(B):
+        ref_out, ref_eig = oracle.compute_pca_features(host[b], nb, normalize, return_eig=True)
+        ties += compare_set(out[b], eig[b], ref_out, ref_eig, N)
+    assert ties <= 2
+
+
+def test_ragged_batch_and_2d(gpu, oracle):
+    import torch
+    eng = pkg("engine")
+    rng = np.random.default_rng(9)
+    sizes = [3, 1024, 2, 77, 5000, 2048, 2049, 1, 0, 300]
+    sets = [(rng.normal(size=(n, 3)) * np.array([1.0, 0.4, 0.1])).astype(np.float32) for n in sizes]
+    off = np.zeros(len(sizes) + 1, dtype=np.int64)
+    np.cumsum(sizes, out=off[1:])
+    flat = torch.from_numpy(np.concatenate(sets)).to(gpu)
+    res = eng.pca_batch(flat, torch.from_numpy(off).to(gpu), 8, False, eig=True)
+    out, eig = res["out"].cpu().numpy(), res["eig"].cpu().numpy()
+    for b, n in enumerate(sizes):
+        if n < 3:
+            assert np.isnan(out[b]).all()
+            continue
+        ref_out, ref_eig = oracle.compute_pca_features(sets[b].astype(np.float64), 8, False, return_eig=True)
+        compare_set(out[b], eig[b], ref_out, ref_eig, n)
+    # 2-D input == 3-D input with z = 0
+    p2 = (rng.normal(size=(4, 500, 2)) * np.array([2.0, 0.5])).astype(np.float32)
+    r2 = eng.pca_batch(torch.from_numpy(p2).to(gpu), None, 8, False, eig=True)
+    p3 = np.concatenate([p2, np.zeros((4, 500, 1), np.float32)], axis=2)
+    r3 = eng.pca_batch(torch.from_numpy(p3).to(gpu), None, 8, False, eig=True)
+    assert torch.equal(r2["out"], r3["out"]) and torch.equal(r2["eig"], r3["eig"])
+    assert torch.all(r2["eig"][:, 2] == 0)
+
+
+def test_full_size_properties(gpu):
+    """C4-sized batch: invariants that need no CPU pass.  Rotating a cloud
+    leaves the eigenvalues unchanged; the histogram sums to one; r1+r2+r3 = 1."""
+    import torch
+    eng = pkg("engine")
+    B, N = 100_000, 1024
+    pts = eng.synth_points(B, N, seed=42, device=gpu)
+    res = eng.pca_batch(pts, None, 8, False, eig=True)
+    out, eig = res["out"], res["eig"]
+    assert torch.all(torch.isfinite(out))
+    assert torch.all((out[:, 9:].sum(dim=1) - 1).abs() < 1e-6)
+    assert torch.all((out[:, 3:6].sum(dim=1) - 1).abs() < 1e-6)
+    assert torch.all(eig[:, 0] >= eig[:, 1]) and torch.all(eig[:, 1] >= eig[:, 2]) and torch.all(eig[:, 2] >= 0)
+    # permutation of the coordinate axes is an exact rotation in float32
+    perm = pts[:, :, [2, 0, 1]].contiguous()
+    eig2 = eng.pca_batch(perm, None, 8, False, eig=True)["eig"]
+    assert torch.all((eig2[:, :3] - eig[:, :3]).abs() <= 1e-12 * eig[:, :1])
