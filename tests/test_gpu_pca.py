@@ -43,8 +43,8 @@ def test_reference_golden_vectors(gpu, oracle, pca_golden):
         np.testing.assert_array_equal(ref_out, case["out"])  # oracle == reference output
         degenerate = ref_eig[2] <= 1e-9 * max(ref_eig[0], 1e-300)
         ties += compare_set(out[0], eig[0], case["out"], ref_eig, pts.shape[0], strict_rel=not degenerate)
-        if ref_eig[2] == 0.0:
-            assert eig[0][2] == 0.0  # planar / collinear sets: exact zero like LAPACK
+        if np.all(pts[:, 2] == pts[0, 2]):
+            assert eig[0][2] == 0.0 and ref_eig[2] == 0.0  # a constant coordinate gives an exact zero, as LAPACK does
     assert ties <= 1
 
 

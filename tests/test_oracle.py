@@ -1,0 +1,127 @@
+"""The CPU oracle against the reference's own outputs and artefacts (no GPU)."""
+import csv
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, pkg
+
+
+def test_pca_restatement_equals_reference_outputs(oracle, pca_golden):
+    """tests/golden/pca_golden.npz holds outputs of the reference's
+    compute_pca_features; the restatement must reproduce them bit for bit."""
+    assert len(pca_golden) >= 15
+    for case in pca_golden:
+        out = oracle.compute_pca_features(case["pts"], case["n_bins"], case["normalize"])
+        assert out.dtype == np.float32 and out.shape == (9 + case["n_bins"],)
+        np.testing.assert_array_equal(out, case["out"])
+
+
+def test_pca_too_few_points_message(oracle):
+    msg = (GOLDEN / "pca_too_few_message.txt").read_text().strip()
+    with pytest.raises(ValueError) as e:
+        oracle.compute_pca_features(np.zeros((2, 3)))
+    assert str(e.value) == msg
+
+
+def test_hu_c_and_numpy_restatements_agree(oracle, c_oracle, hu_panels):
+    masks = hu_panels["masks"]
+    c = c_oracle.hu_batch(masks)
+    for i in range(masks.shape[0]):
+        m = oracle.moments_u8(masks[i])
+        np.testing.assert_array_equal(m, c["moments24"][i])
+        np.testing.assert_array_equal(oracle.hu_from_moments(m), c["hu7"][i])
+        np.testing.assert_array_equal(oracle.compute_hu_from_image(masks[i]), c["hulog7"][i])
+
+
+def test_hu_opencv_tile_order_equals_exact_integers(c_oracle, hu_panels):
+    """Up to 512x512 every partial sum of OpenCV's tile accumulation is an
+    integer below 2^53, so its result equals the exact integer moments."""
+    synth = pkg("synth")
+    for imgs in (hu_panels["masks"], hu_panels["preproc"], synth.shapes_host(3, 512, 512, seed=3),
+                 np.full((1, 512, 512), 255, np.uint8)):
+        a, b = c_oracle.hu_batch(imgs), c_oracle.hu_batch(imgs, exact=True)
+        np.testing.assert_array_equal(a["moments24"], b["moments24"])
+        np.testing.assert_array_equal(a["hu7"], b["hu7"])
+
+
+def test_hu_large_image_tile_order_close_to_exact(c_oracle):
+    """Beyond 2^53 OpenCV's double accumulation rounds per tile; the exact
+    integers it approximates stay within 1e-12 relative."""
+    img = pkg("synth").shapes_host(1, 2048, 2048, seed=5)
+    a, b = c_oracle.hu_batch(img), c_oracle.hu_batch(img, exact=True)
+    np.testing.assert_allclose(a["moments24"][:, :10], b["moments24"][:, :10], rtol=1e-12)
+    np.testing.assert_allclose(a["hulog7_f64"][:, :4], b["hulog7_f64"][:, :4], rtol=1e-9)
+
+
+def test_hu_matches_textbook_definition(oracle, c_oracle, hu_panels):
+    """Independent check of the OpenCV-order formulas: central moments summed
+    directly from their definition."""
+    imgs = np.concatenate([hu_panels["masks"][:6], hu_panels["preproc"][:3]])
+    c = c_oracle.hu_batch(imgs)
+    for i in range(imgs.shape[0]):
+        tb = oracle.hu_textbook(imgs[i])
+        np.testing.assert_allclose(c["hu7"][i, :2], tb[:2], rtol=1e-9)
+        # h3..h7 are differences of small quantities: compare on the scale of their terms
+        scale = np.abs(c["hu7"][i, 0]) ** np.array([3, 3, 6, 4, 6])
+        assert np.all(np.abs(c["hu7"][i, 2:] - tb[2:]) <= 1e-9 * scale + 1e-6 * np.abs(tb[2:]))
+
+
+def test_hu_weight_and_axis_convention_against_committed_table(c_oracle, hu_panels):
+    """The reference's feature table holds the 12-view mean/std of log-Hu per
+    id; the panels are view_01 of 21 of those ids.  With pixel value as weight
+    (0/255) view_01 sits within a few standard deviations of the table mean;
+    with 0/1 weights hu1 would be off by log10(255) = 2.41."""
+    rows = {r["id"]: r for r in csv.DictReader(open(GOLDEN / "hu_table_rows.csv"))}
+    got = c_oracle.hu_batch(hu_panels["masks"])["hulog7"]
+    z1, z2 = [], []
+    for i, sid in enumerate(hu_panels["ids"]):
+        r = rows[sid]
+        z1.append((got[i, 0] - float(r["hu1_mean"])) / max(float(r["hu1_std"]), 1e-3))
+        z2.append((got[i, 1] - float(r["hu2_mean"])) / max(float(r["hu2_std"]), 1e-3))
+        assert abs(got[i, 0] - float(r["hu1_mean"])) < 0.4  # nowhere near the 2.41 of the other convention
+    assert np.median(np.abs(z1)) < 2.0 and np.median(np.abs(z2)) < 2.0
+    binary01 = c_oracle.hu_batch((hu_panels["masks"] // 255).astype(np.uint8))["hulog7"]
+    np.testing.assert_allclose(got[:, 0] - binary01[:, 0], np.log10(255.0), atol=1e-5)
+
+
+def test_hu_distribution_matches_reference_run(c_oracle, hu_panels):
+    """hu_feature_stats.csv: mean/std over the reference's 557 samples."""
+    stats = {r["feature"]: (float(r["mean"]), float(r["std"])) for r in csv.DictReader(open(GOLDEN / "hu_feature_stats.csv"))}
+    got = c_oracle.hu_batch(hu_panels["masks"])["hulog7"]
+    for j in range(4):
+        mean, std = stats[f"hu{j + 1}_mean"]
+        assert abs(got[:, j].mean() - mean) < 3 * std
+
+
+def test_groupstat_restatements(oracle, c_oracle):
+    rng = np.random.default_rng(0)
+    rows = rng.normal(size=(40, 7)).astype(np.float32) * 5
+    off = [0, 12, 24, 40]
+    np.testing.assert_array_equal(c_oracle.hu_groupstat(rows, off), oracle.hu_groupstat(rows, off))
+    one = oracle.hu_groupstat(rows[:12])
+    np.testing.assert_array_equal(one[0, :7], np.mean(rows[:12], axis=0))
+    np.testing.assert_array_equal(one[0, 7:], np.std(rows[:12], axis=0, ddof=0))
+
+
+def test_contour_points_restatements(oracle, c_oracle, hu_panels):
+    for img in list(hu_panels["masks"][:4]) + [np.zeros((9, 9), np.uint8), np.full((5, 7), 255, np.uint8)]:
+        np.testing.assert_array_equal(c_oracle.contour_points(img), oracle.contour_points(img))
+    full = oracle.contour_points(np.full((5, 7), 255, np.uint8))
+    assert full.shape[0] == 2 * 7 + 2 * 3  # the image border of a full image
+    img = np.zeros((20, 20), np.uint8)
+    img[5:15, 5:15] = 255
+    assert oracle.contour_points(img).shape[0] == 36
+    vec = oracle.contour_pca_features(img)
+    assert vec.shape == (17,) and vec[2] == 0.0 and abs(vec[9:].sum() - 1) < 1e-6
+    assert np.isnan(oracle.contour_pca_features(np.zeros((8, 8), np.uint8))).all()
+
+
+def test_empty_and_degenerate_hu(oracle, c_oracle):
+    z = c_oracle.hu_batch(np.zeros((1, 16, 16), np.uint8))
+    assert np.all(z["hulog7"] == 0) and np.all(z["moments24"] == 0)
+    one = np.zeros((1, 16, 16), np.uint8)
+    one[0, 3, 4] = 200
+    r = c_oracle.hu_batch(one)
+    assert r["moments24"][0, 0] == 200 and r["moments24"][0, 1] == 800 and r["moments24"][0, 2] == 600
+    assert np.all(r["hu7"] == 0) and np.all(r["hulog7"] == 0)
