@@ -13,6 +13,8 @@
 // wave shuffles + LDS for the block reduction.  No MFMA.
 #include "fx_common.h"
 #include "fx_eig.h"
+#include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -38,6 +40,13 @@ struct HuArgs {
     int rpp;   // rows per pass = 256 / cpr
     int wpr;   // 32-bit mask words per row = ceil(cpr / 2)
     int wrpp;  // mask rows per pass = 256 / wpr
+    // band kernel: each wave holds bpw bands of cpr lanes; a band is hb
+    // consecutive rows; qcap entries fit in the contour queue
+    int bpw, nbands, hb, qcap;
+    // per-image flag: 1 = the band kernel's contour queue overflowed and the
+    // image has to be redone by the mask kernel
+    uint8_t *redo;
+    int only_redo;  // mask kernel: skip images whose flag is 0
 };
 
 constexpr int MODE_GRAY = 0;     // weight = pixel value
@@ -309,6 +318,8 @@ __global__ __launch_bounds__(FX_BLOCK) void hu_image_kernel(HuArgs A)
 
     const int t = threadIdx.x;
     const int64_t b = blockIdx.x;
+    if (A.only_redo && A.redo[b] == 0)
+        return;
     const uint8_t *img = A.img + b * A.stride;
     const int H = A.H, W = A.W;
 
@@ -536,6 +547,307 @@ __global__ __launch_bounds__(FX_BLOCK) void hu_image_kernel(HuArgs A)
     }
 }
 
+
+// ------------------------------------------------------------ band kernel
+// Faster organisation for images up to 1024 pixels wide.  A row of the image
+// (cpr chunks) sits in cpr adjacent lanes of one wave; each group of cpr lanes
+// owns a band of hb consecutive rows and walks down it.  A lane therefore has
+// the rows above and below in its own registers and the chunks left and right
+// in the neighbouring lanes, so contour pixels are found while the image
+// streams in and only the contour segments (16-pixel masks with at least one
+// contour pixel, about 0.5 % of the chunks) go to LDS, into a queue that the
+// whole block then works through evenly.
+constexpr int BAND_LDS_COUNTERS = LDS_HEAD_BYTES;          // 16 B: queue length
+constexpr int BAND_LDS_EDGES = BAND_LDS_COUNTERS + 16;     // top/bottom row masks of every band
+
+template <int MODE, bool CONTOUR, bool ALIGNED>
+__global__ __launch_bounds__(FX_BLOCK) void hu_band_kernel(HuArgs A)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    u64 *red = reinterpret_cast<u64 *>(lds_raw);
+    double *bcast = reinterpret_cast<double *>(lds_raw + LDS_RED_BYTES);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(lds_raw + LDS_RED_BYTES + LDS_BCAST_BYTES);
+    uint32_t *qlen = reinterpret_cast<uint32_t *>(lds_raw + BAND_LDS_COUNTERS);
+    uint16_t *edge_top = reinterpret_cast<uint16_t *>(lds_raw + BAND_LDS_EDGES);
+    uint16_t *edge_bot = edge_top + FX_BLOCK;
+    uint32_t *queue = reinterpret_cast<uint32_t *>(lds_raw + BAND_LDS_EDGES + 4 * FX_BLOCK);
+
+    const int t = threadIdx.x;
+    const int lane = fx_lane(), wave = fx_wave();
+    const int64_t b = blockIdx.x;
+    const uint8_t *img = A.img + b * A.stride;
+    const int H = A.H, W = A.W, cpr = A.cpr, hb = A.hb;
+
+    const int bl = lane / cpr, tx = lane - bl * cpr;
+    const bool active = bl < A.bpw;
+    const int band = wave * A.bpw + bl;
+    const int ya = band * hb;
+    const int x0 = tx * 16;
+    const uint32_t kthr = (uint32_t)(255 - (A.thresh < 0 ? 127 : A.thresh)) * 0x00010001u;
+
+    if (CONTOUR) {
+        if (t < 64)
+            hist[t] = 0;
+        if (t == 0)
+            qlen[0] = 0;
+        __syncthreads();
+    }
+
+    const bool full = ALIGNED && (x0 + 16 <= W);
+    auto load_chunk = [&](int r) -> uint4 {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        const int y = ya + r;
+        if (active && r < hb && y < H) {
+            const uint8_t *p = img + (int64_t)y * A.pitch + x0;
+            if (full) {
+                v = *reinterpret_cast<const uint4 *>(p);
+            } else {
+                uint32_t w[4] = {0, 0, 0, 0};
+                int n = W - x0;
+                n = n > 16 ? 16 : n;
+                for (int k = 0; k < n; k++)
+                    w[k >> 2] |= (uint32_t)p[k] << (8 * (k & 3));
+                v = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        }
+        return v;
+    };
+
+    // Contour pixels of one row of the band: foreground with a 4-neighbour
+    // that is background.  Must be called by every lane of the wave.
+    auto detect = [&](int r, uint32_t up, uint32_t cur, uint32_t dn) {
+        const uint32_t lc = (uint32_t)__shfl_up((int)cur, 1, FX_WAVE);
+        const uint32_t rc = (uint32_t)__shfl_down((int)cur, 1, FX_WAVE);
+        const uint32_t lbit = tx > 0 ? (lc >> 15) & 1u : 0u;
+        const uint32_t rbit = tx < cpr - 1 ? (rc & 1u) : 0u;
+        const uint32_t left = ((cur << 1) | lbit) & 0xFFFFu;
+        const uint32_t right = (cur >> 1) | (rbit << 15);
+        const uint32_t bits = cur & ~(up & dn & left & right);
+        if (bits) {
+            const uint32_t idx = atomicAdd(qlen, 1u);
+            if (idx < (uint32_t)A.qcap)
+                queue[idx] = bits | ((uint32_t)((ya + r) * cpr + tx) << 16);
+        }
+    };
+
+    Tot64 T;
+    T.clear();
+    uint32_t c_prev = 0, c_cur = 0, c_first = 0, c_second = 0;
+    auto contour_row = [&](int r, uint32_t c) {  // r is wave-uniform
+        if (r == 0)
+            c_first = c;
+        if (r == 1)
+            c_second = c;
+        if (r >= 2)
+            detect(r - 1, c_prev, c_cur, c);
+        c_prev = c_cur;
+        c_cur = c;
+    };
+
+    for (int jb = 0; jb < hb; jb += 32) {
+        Acc32 a;
+        a.clear();
+#pragma unroll 1
+        for (int j = 0; j < 32 && jb + j < hb; j += 4) {
+            const int r = jb + j;
+            uint4 v0 = load_chunk(r);
+            uint4 v1 = load_chunk(r + 1);
+            uint4 v2 = load_chunk(r + 2);
+            uint4 v3 = load_chunk(r + 3);
+            uint32_t b0, b1, b2, b3;
+            chunk_sums<MODE>(v0, kthr, j, a, b0);
+            chunk_sums<MODE>(v1, kthr, j + 1, a, b1);
+            chunk_sums<MODE>(v2, kthr, j + 2, a, b2);
+            chunk_sums<MODE>(v3, kthr, j + 3, a, b3);
+            if (CONTOUR) {
+                contour_row(r, b0);
+                if (r + 1 < hb)
+                    contour_row(r + 1, b1);
+                if (r + 2 < hb)
+                    contour_row(r + 2, b2);
+                if (r + 3 < hb)
+                    contour_row(r + 3, b3);
+            }
+        }
+        flush(a, (u64)(ya + jb), 1ull, T);
+    }
+
+    u64 M[10];
+    {
+        const u64 X = (u64)x0, X2 = X * X, X3 = X2 * X;
+        M[0] = T.t00;
+        M[1] = X * T.t00 + T.t10;
+        M[2] = T.t01;
+        M[3] = X2 * T.t00 + 2 * X * T.t10 + T.t20;
+        M[4] = X * T.t01 + T.t11;
+        M[5] = T.t02;
+        M[6] = X3 * T.t00 + 3 * X2 * T.t10 + 3 * X * T.t20 + T.t30;
+        M[7] = X2 * T.t01 + 2 * X * T.t11 + T.t21;
+        M[8] = X * T.t02 + T.t12;
+        M[9] = T.t03;
+    }
+    if (CONTOUR) {
+        // rows 0 and hb-1 of every band still miss their neighbour row in the
+        // adjacent band: publish them
+        edge_top[t] = (uint16_t)c_first;
+        edge_bot[t] = (uint16_t)c_cur;
+    }
+    block_sum_u64<10>(M, red);  // its barriers also publish the edge rows
+
+    if (t == 0) {
+        const u64 scale = (MODE == MODE_GRAY) ? 1ull : (u64)A.on_value;
+        double raw[10];
+#pragma unroll
+        for (int k = 0; k < 10; k++)
+            raw[k] = (double)(M[k] * scale);
+        finalize_moments(raw, A.moments24 ? A.moments24 + b * 24 : nullptr,
+                         A.hu7 ? A.hu7 + b * 7 : nullptr, A.hulog7 ? A.hulog7 + b * 7 : nullptr);
+    }
+    if (!CONTOUR)
+        return;
+
+    {
+        // the thread that holds the same columns in the band above / below
+        const int above = t - cpr + ((bl == 0) ? (cpr * A.bpw - FX_WAVE) : 0);
+        const int below = t + cpr + ((bl == A.bpw - 1) ? (FX_WAVE - cpr * A.bpw) : 0);
+        const uint32_t up_ext = (active && band > 0) ? edge_bot[above] : 0u;
+        const uint32_t dn_ext = (active && band + 1 < A.nbands) ? edge_top[below] : 0u;
+        if (hb == 1) {
+            detect(0, up_ext, c_first, dn_ext);
+        } else {
+            detect(0, up_ext, c_first, c_second);
+            detect(hb - 1, c_prev, c_cur, dn_ext);
+        }
+    }
+    __syncthreads();
+
+    const uint32_t qn_raw = qlen[0];
+    if (A.redo && t == 0)
+        A.redo[b] = qn_raw > (uint32_t)A.qcap ? 1 : 0;
+    if (qn_raw > (uint32_t)A.qcap)
+        return;  // the mask kernel redoes this image
+    const int qn = (int)qn_raw;
+    const int nb = A.n_bins;
+    const int64_t row = b * (9 + nb);
+
+    // ---- sums over contour pixels: n, sum x, sum y, sum x^2, sum xy, sum y^2
+    u64 S[6] = {0, 0, 0, 0, 0, 0};
+    {
+        uint32_t s0 = 0, sx = 0, sy = 0, sxx = 0, sxy = 0, syy = 0;  // <= 16 entries per thread: fits 32 bits
+        for (int i = t; i < qn; i += FX_BLOCK) {
+            const uint32_t e = queue[i];
+            const uint32_t bits = e & 0xFFFFu, pos = e >> 16;
+            const uint32_t y = pos / (uint32_t)cpr, X = (pos - y * cpr) * 16u;
+            const uint32_t p0 = __popc(bits & 0xAAAAu), p1 = __popc(bits & 0xCCCCu);
+            const uint32_t p2 = __popc(bits & 0xF0F0u), p3 = __popc(bits & 0xFF00u);
+            const uint32_t r0 = __popc(bits);
+            const uint32_t r1 = p0 + 2 * p1 + 4 * p2 + 8 * p3;
+            uint32_t r2 = p0 + 4 * p1 + 16 * p2 + 64 * p3;
+            r2 += 4 * __popc(bits & 0xAAAAu & 0xCCCCu) + 8 * __popc(bits & 0xAAAAu & 0xF0F0u);
+            r2 += 16 * __popc(bits & 0xAAAAu & 0xFF00u) + 16 * __popc(bits & 0xCCCCu & 0xF0F0u);
+            r2 += 32 * __popc(bits & 0xCCCCu & 0xFF00u) + 64 * __popc(bits & 0xF0F0u & 0xFF00u);
+            const uint32_t ex = X * r0 + r1;  // sum of x over the segment
+            s0 += r0;
+            sx += ex;
+            sy += y * r0;
+            sxx += X * X * r0 + 2 * X * r1 + r2;
+            sxy += y * ex;
+            syy += y * y * r0;
+        }
+        S[0] = s0;
+        S[1] = sx;
+        S[2] = sy;
+        S[3] = sxx;
+        S[4] = sxy;
+        S[5] = syy;
+    }
+    block_sum_u64<6>(S, red);
+
+    const u64 n = S[0];
+    if (n < 3) {
+        const float nanv = __builtin_nanf("");
+        for (int i = t; i < 9 + nb; i += FX_BLOCK)
+            A.cpca[row + i] = nanv;
+        if (A.ceig && t < 6)
+            A.ceig[b * 6 + t] = __builtin_nan("");
+        return;
+    }
+    if (t == 0) {
+        const double dn = (double)n;
+        const double inv = 1.0 / (dn * (double)(n - 1));
+        const i64 sx = (i64)S[1], sy = (i64)S[2];
+        const double cxx = (double)((i64)(n * S[3]) - sx * sx) * inv;
+        const double cxy = (double)((i64)(n * S[4]) - sx * sy) * inv;
+        const double cyy = (double)((i64)(n * S[5]) - sy * sy) * inv;
+        double lam[3], v1[3], head[9];
+        fx_eig3(cxx, cxy, 0.0, cyy, 0.0, 0.0, lam, v1);
+        fx_pca_head(lam, head);
+        for (int i = 0; i < 9; i++)
+            A.cpca[row + i] = (float)head[i];
+        if (A.ceig) {
+            for (int i = 0; i < 3; i++) {
+                A.ceig[b * 6 + i] = lam[i];
+                A.ceig[b * 6 + 3 + i] = v1[i];
+            }
+        }
+        bcast[0] = (double)S[1] / dn;
+        bcast[1] = (double)S[2] / dn;
+        bcast[2] = v1[0];
+        bcast[3] = v1[1];
+    }
+    __syncthreads();
+    const double ccx = bcast[0], ccy = bcast[1], vx = bcast[2], vy = bcast[3];
+
+    // signed projection of pixel (X + i, y); monotone in i
+    auto sproj = [&](uint32_t X, int i, double dyv) -> double {
+        return fma(dyv, vy, ((double)(int)(X + i) - ccx) * vx);
+    };
+
+    // ---- largest |projection|: at an end of each segment --------------------
+    double top = 0.0;
+    for (int i = t; i < qn; i += FX_BLOCK) {
+        const uint32_t e = queue[i];
+        const uint32_t bits = e & 0xFFFFu, pos = e >> 16;
+        const uint32_t y = pos / (uint32_t)cpr, X = (pos - y * cpr) * 16u;
+        const double dy = (double)(int)y - ccy;
+        const int lo = __ffs((int)bits) - 1, hi = 31 - __clz((int)bits);
+        top = fmax(top, fmax(fabs(sproj(X, lo, dy)), fabs(sproj(X, hi, dy))));
+    }
+    top = block_max_f64(top, reinterpret_cast<double *>(red));
+
+    if (top > 0.0) {
+        const double step = top / (double)nb;
+        const double inv_step = (double)nb / top;
+        for (int i = t; i < qn; i += FX_BLOCK) {
+            const uint32_t e = queue[i];
+            const uint32_t bits = e & 0xFFFFu, pos = e >> 16;
+            const uint32_t y = pos / (uint32_t)cpr, X = (pos - y * cpr) * 16u;
+            const double dy = (double)(int)y - ccy;
+            int lo = __ffs((int)bits) - 1;
+            const int hi = 31 - __clz((int)bits);
+            const double slo = sproj(X, lo, dy), shi = sproj(X, hi, dy);
+            int blo = fx_hist_bin(fabs(slo), step, inv_step, nb);
+            const int bhi = fx_hist_bin(fabs(shi), step, inv_step, nb);
+            if (blo == bhi && ((slo < 0.0) == (shi < 0.0))) {
+                // |projection| is monotone between the two ends: one bin for the segment
+                atomicAdd(&hist[blo], (uint32_t)__popc(bits));
+            } else {
+                uint32_t rest = bits;
+                while (rest) {
+                    const int k = __ffs((int)rest) - 1;
+                    rest &= rest - 1;
+                    atomicAdd(&hist[fx_hist_bin(fabs(sproj(X, k, dy)), step, inv_step, nb)], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        if (t < nb)
+            A.cpca[row + 9 + t] = (float)((double)hist[t] / (double)n);
+    } else if (t < nb) {
+        A.cpca[row + 9 + t] = t == 0 ? 1.0f : 0.0f;
+    }
+}
+
 __global__ void hu_groupstat_kernel(const float *hulog7, const int64_t *offsets, int64_t G, float *out14)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -575,6 +887,34 @@ int launch_image_kernel(const HuArgs &A, bool aligned, size_t lds, hipStream_t s
     }
     FX_HIP_CHECK(hipGetLastError());
     return FX_OK;
+}
+
+template <int MODE, bool CONTOUR>
+int launch_band_kernel(const HuArgs &A, bool aligned, size_t lds, hipStream_t s)
+{
+    dim3 grid((unsigned)A.B), block(FX_BLOCK);
+    if (aligned)
+        hipLaunchKernelGGL((hu_band_kernel<MODE, CONTOUR, true>), grid, block, lds, s, A);
+    else
+        hipLaunchKernelGGL((hu_band_kernel<MODE, CONTOUR, false>), grid, block, lds, s, A);
+    FX_HIP_CHECK(hipGetLastError());
+    return FX_OK;
+}
+
+template <bool BAND>
+int launch_hu(const HuArgs &A, int mode, bool contour, bool aligned, size_t lds, hipStream_t s)
+{
+#define FX_PICK(FN)                                                                        \
+    (contour ? (mode == MODE_GRAY   ? FN<MODE_GRAY, true>(A, aligned, lds, s)              \
+                : mode == MODE_BIT7 ? FN<MODE_BIT7, true>(A, aligned, lds, s)              \
+                                    : FN<MODE_THRESH, true>(A, aligned, lds, s))           \
+             : (mode == MODE_GRAY   ? FN<MODE_GRAY, false>(A, aligned, lds, s)             \
+                : mode == MODE_BIT7 ? FN<MODE_BIT7, false>(A, aligned, lds, s)             \
+                                    : FN<MODE_THRESH, false>(A, aligned, lds, s)))
+    if (BAND)
+        return FX_PICK(launch_band_kernel);
+    return FX_PICK(launch_image_kernel);
+#undef FX_PICK
 }
 
 }  // namespace
@@ -627,22 +967,40 @@ extern "C" int fx_hu_batch_u8(const uint8_t *d_img, int64_t B, int H, int W, int
     }
     A.rpp = FX_BLOCK / A.cpr;
     A.wrpp = FX_BLOCK / A.wpr;
+    A.redo = nullptr;
+    A.only_redo = 0;
     const bool aligned = ((uintptr_t)d_img % 16 == 0) && (pitch_bytes % 16 == 0) && (img_stride_bytes % 16 == 0 || B == 1);
-    const size_t lds = LDS_HEAD_BYTES + mask_bytes;
+    const size_t mask_lds = LDS_HEAD_BYTES + mask_bytes;
     const int mode = thresh < 0 ? MODE_GRAY : (thresh == 127 ? MODE_BIT7 : MODE_THRESH);
 
+    // Band kernel: a row must fit in one wave and a queue position in 16 bits.
+    bool band = A.cpr <= FX_WAVE && (int64_t)H * A.cpr <= 65536;
+    const char *force = getenv("FX_HU_KERNEL");  // "mask" or "band": development switch
+    if (force && strcmp(force, "mask") == 0)
+        band = false;
+    A.bpw = band ? FX_WAVE / A.cpr : 0;
+    A.nbands = A.bpw * FX_WAVES_PER_BLOCK;
+    A.hb = band ? (H + A.nbands - 1) / A.nbands : 0;
+    const int64_t segments = (int64_t)H * A.cpr;
+    A.qcap = (int)(segments < 4096 ? segments : 4096);
+
     FxProfileScope prof(s);
-    int rc;
-    if (contour) {
-        rc = mode == MODE_GRAY   ? launch_image_kernel<MODE_GRAY, true>(A, aligned, lds, s)
-             : mode == MODE_BIT7 ? launch_image_kernel<MODE_BIT7, true>(A, aligned, lds, s)
-                                 : launch_image_kernel<MODE_THRESH, true>(A, aligned, lds, s);
-    } else {
-        rc = mode == MODE_GRAY   ? launch_image_kernel<MODE_GRAY, false>(A, aligned, lds, s)
-             : mode == MODE_BIT7 ? launch_image_kernel<MODE_BIT7, false>(A, aligned, lds, s)
-                                 : launch_image_kernel<MODE_THRESH, false>(A, aligned, lds, s);
+    if (!band)
+        return launch_hu<false>(A, mode, contour, aligned, mask_lds, s);
+
+    const bool may_overflow = contour && A.qcap < segments;
+    if (may_overflow) {
+        A.redo = (uint8_t *)fx_scratch((size_t)B, 1);
+        if (!A.redo)
+            return FX_ENOMEM;
     }
-    return rc;
+    const size_t band_lds = contour ? (size_t)BAND_LDS_EDGES + 4 * FX_BLOCK + (size_t)A.qcap * 4 : (size_t)LDS_HEAD_BYTES;
+    int rc = launch_hu<true>(A, mode, contour, aligned, band_lds, s);
+    if (rc != FX_OK || !may_overflow)
+        return rc;
+    // images whose contour queue overflowed (very ragged masks) go through the mask kernel
+    A.only_redo = 1;
+    return launch_hu<false>(A, mode, contour, aligned, mask_lds, s);
 }
 
 extern "C" int fx_hu_groupstat(const float *d_hulog7, const int64_t *d_group_offsets, int64_t G, float *d_out14,

@@ -127,6 +127,23 @@ def test_contour_descriptor(gpu, oracle, size, nb):
     assert ties <= 2
 
 
+def test_ragged_masks_overflow_path(gpu, oracle, c_oracle):
+    """Noise images have a contour segment in almost every 16-pixel chunk, far
+    beyond the on-chip segment queue: such images are redone by the mask kernel."""
+    rng = np.random.default_rng(17)
+    imgs = pkg("synth").shapes_host(4, 512, 512, seed=33)
+    imgs[1] = (rng.integers(0, 2, size=(512, 512)) * 255).astype(np.uint8)
+    imgs[3] = (rng.integers(0, 4, size=(512, 512)) == 0).astype(np.uint8) * 255
+    got = run_gpu(gpu, imgs, thresh=127, contour_bins=8, contour_eig=True)
+    check_against_oracle(got, c_oracle.hu_batch(imgs, thresh=127))
+    for b in range(4):
+        ref, eig = oracle.contour_pca_features(imgs[b], 127, 8, return_eig=True)
+        assert np.all(np.abs(got["ceig"][b, :3] - eig[:3]) <= 1e-9 * eig[0])
+        np.testing.assert_allclose(got["cpca"][b, :9], ref[:9], rtol=1e-6, atol=1e-30)
+        n = oracle.contour_points(imgs[b]).shape[0]
+        assert (np.abs(got["cpca"][b, 9:].astype(np.float64) - ref[9:]) * n).max() <= 2.5
+
+
 def test_full_size_properties(gpu):
     """C2/C3-sized batches: properties that need no CPU pass over the data.
     Raw moments are additive over disjoint masks and the Hu vector is invariant

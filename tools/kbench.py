@@ -1,0 +1,41 @@
+"""Kernel timing harness for development: times hu_batch / pca_batch variants with HIP events."""
+import importlib, os, sys, time
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch
+eng = importlib.import_module("image-processing_amd.engine")
+dev = torch.device("cuda", 0)
+
+def time_hu(B, H, W, contour, reps=8, thresh=127):
+    imgs = eng.synth_shapes(B, H, W, seed=42, device=dev)
+    kw = dict(contour_bins=8) if contour else {}
+    for _ in range(2): eng.hu_batch(imgs, thresh=thresh, **kw)
+    torch.cuda.synchronize()
+    eng.profile(True); ms = []
+    for _ in range(reps):
+        eng.hu_batch(imgs, thresh=thresh, **kw); ms.append(eng.profile_last_ms())
+    eng.profile(False)
+    ms.sort(); med = ms[len(ms)//2]
+    return med, B*H*W/med/1e6
+
+def time_pca(B, N, reps=8):
+    pts = eng.synth_points(B, N, seed=42, device=dev)
+    for _ in range(2): eng.pca_batch(pts)
+    torch.cuda.synchronize()
+    eng.profile(True); ms = []
+    for _ in range(reps):
+        eng.pca_batch(pts); ms.append(eng.profile_last_ms())
+    eng.profile(False)
+    ms.sort(); med = ms[len(ms)//2]
+    return med, B*N*12/med/1e6
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "hu"
+    if what == "hu":
+        for (B,H,W,c) in [(30000,512,512,False),(30000,512,512,True),(100000,256,256,False),(100000,256,256,True)]:
+            ms, gbps = time_hu(B,H,W,c)
+            print(f"hu B={B} {H}x{W} contour={c} dbg={os.environ.get('FX_DBG','0')}: {ms:.3f} ms  {gbps:.0f} GB/s", flush=True)
+    else:
+        for (B,N) in [(300000,1024),(100000,2048),(1000000,256)]:
+            ms, gbps = time_pca(B,N)
+            print(f"pca B={B} N={N}: {ms:.3f} ms  {gbps:.0f} GB/s", flush=True)
