@@ -43,11 +43,13 @@ struct HuArgs {
     // band kernel: each wave holds bpw bands of cpr lanes; a band is hb
     // consecutive rows; qcap entries fit in the contour queue
     int bpw, nbands, hb, qcap;
-    // per-image flag: 1 = the band kernel's contour queue overflowed and the
-    // image has to be redone by the mask kernel
-    uint8_t *redo;
-    int only_redo;  // mask kernel: skip images whose flag is 0
+    // segments the band kernel found per image; above qcap its queue
+    // overflowed and the mask kernel has to redo the image
+    const uint32_t *redo;
+    int only_redo;  // mask kernel: skip images that did not overflow
 };
+
+__device__ __forceinline__ bool band_overflowed(const uint32_t *qcount, int64_t b, int qcap);
 
 constexpr int MODE_GRAY = 0;     // weight = pixel value
 constexpr int MODE_BIT7 = 1;     // weight = on_value * (pixel > 127)
@@ -105,20 +107,21 @@ __device__ __forceinline__ void chunk_sums(const uint4 &v, uint32_t kthr, uint32
 {
     uint32_t w[4] = {v.x, v.y, v.z, v.w};
     uint32_t src[4];
-    uint32_t nib[4];
+    uint32_t fg[4];  // 0/1 per byte: foreground of the contour mask
 #pragma unroll
     for (int d = 0; d < 4; d++) {
         if (MODE == MODE_THRESH) {
-            uint32_t m = gt_bytes(w[d], kthr);
-            src[d] = m;
-            nib[d] = (m * 0x01020408u) >> 24;  // bytes 0/1 -> 4 bits
+            fg[d] = gt_bytes(w[d], kthr);
+            src[d] = fg[d];
         } else {
-            uint32_t hi = w[d] & 0x80808080u;
-            src[d] = (MODE == MODE_BIT7) ? (hi >> 7) : w[d];
-            nib[d] = (hi * 0x00204081u) >> 28;  // bit 7 of each byte -> 4 bits
+            fg[d] = (w[d] >> 7) & 0x01010101u;
+            src[d] = (MODE == MODE_BIT7) ? fg[d] : w[d];
         }
     }
-    bits16 = (nib[0] & 15u) | ((nib[1] & 15u) << 4) | ((nib[2] & 15u) << 8) | ((nib[3] & 15u) << 12);
+    // byte k of a dword weighs 2^k (low nibble) or 2^(k+4): the dot products are the mask bits
+    const uint32_t lo8 = dot4(fg[1], 0x80402010u, dot4(fg[0], 0x08040201u, 0u));
+    const uint32_t hi8 = dot4(fg[3], 0x80402010u, dot4(fg[2], 0x08040201u, 0u));
+    bits16 = lo8 | (hi8 << 8);
 
     uint32_t s0 = 0, s1 = 0, s2 = 0, s3l = 0, s3h = 0;
 #pragma unroll
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(FX_BLOCK) void hu_image_kernel(HuArgs A)
 
     const int t = threadIdx.x;
     const int64_t b = blockIdx.x;
-    if (A.only_redo && A.redo[b] == 0)
+    if (A.only_redo && !band_overflowed(A.redo, b, A.qcap))
         return;
     const uint8_t *img = A.img + b * A.stride;
     const int H = A.H, W = A.W;
@@ -549,25 +552,58 @@ __global__ __launch_bounds__(FX_BLOCK) void hu_image_kernel(HuArgs A)
 
 
 // ------------------------------------------------------------ band kernel
-// Faster organisation for images up to 1024 pixels wide.  A row of the image
-// (cpr chunks) sits in cpr adjacent lanes of one wave; each group of cpr lanes
-// owns a band of hb consecutive rows and walks down it.  A lane therefore has
-// the rows above and below in its own registers and the chunks left and right
-// in the neighbouring lanes, so contour pixels are found while the image
-// streams in and only the contour segments (16-pixel masks with at least one
-// contour pixel, about 0.5 % of the chunks) go to LDS, into a queue that the
-// whole block then works through evenly.
+// Organisation for images up to 1024 x 1024.  A row of the image (cpr chunks)
+// sits in cpr adjacent lanes of one wave; each group of cpr lanes owns a band
+// of hb consecutive rows and walks down it.  A lane therefore has the rows
+// above and below in its own registers and the chunks left and right in the
+// neighbouring lanes, so contour pixels are found while the image streams in.
+// Only contour segments (16-pixel masks with at least one contour pixel, about
+// 0.5 % of the chunks of a shape image) leave the registers: they go to an LDS
+// queue, the block sums them evenly, and the queue is copied to global scratch.
+//
+// The streaming kernel does no floating point at all.  Two small kernels
+// follow: hu_finalize_kernel (one lane per image: central / normalised
+// moments, Hu, log, contour covariance and eigen-solve -- serial float64 code
+// that would idle 255 of 256 threads inside the streaming kernel) and
+// hu_contour_hist_kernel (one wave per image: |projection| maximum and
+// histogram over the queued segments).
 constexpr int BAND_LDS_COUNTERS = LDS_HEAD_BYTES;          // 16 B: queue length
 constexpr int BAND_LDS_EDGES = BAND_LDS_COUNTERS + 16;     // top/bottom row masks of every band
+constexpr int BAND_SUMS = 16;                              // u64 per image: 10 raw moments + 6 contour sums
+
+struct BandScratch {
+    u64 *sums;         // [B][16]
+    uint32_t *qcount;  // [B][4] segments each wave found (above qcap / 4: the mask kernel redoes the image)
+    uint32_t *queue;   // [B][4][qcap / 4] segment = 16-pixel mask | (y << 6 | chunk) << 16
+    double *params;    // [B][4] contour centroid x, y and first principal axis x, y
+};
+
+__device__ __forceinline__ bool band_overflowed(const uint32_t *qcount, int64_t b, int qcap)
+{
+    const uint32_t wcap = (uint32_t)(qcap >> 2);
+    const uint32_t *c = qcount + b * FX_WAVES_PER_BLOCK;
+    return c[0] > wcap || c[1] > wcap || c[2] > wcap || c[3] > wcap;
+}
+
+// Power sums over the set bits of a 16-pixel segment: count, sum i, sum i^2.
+__device__ __forceinline__ void segment_sums(uint32_t bits, uint32_t &r0, uint32_t &r1, uint32_t &r2)
+{
+    const uint32_t p0 = __popc(bits & 0xAAAAu), p1 = __popc(bits & 0xCCCCu);
+    const uint32_t p2 = __popc(bits & 0xF0F0u), p3 = __popc(bits & 0xFF00u);
+    r0 = __popc(bits);
+    r1 = p0 + 2 * p1 + 4 * p2 + 8 * p3;
+    // i^2 = sum_k 4^k b_k + sum_{j<k} 2^(j+k+1) b_j b_k over the bits b of i
+    r2 = p0 + 4 * p1 + 16 * p2 + 64 * p3;
+    r2 += 4 * __popc(bits & 0xAAAAu & 0xCCCCu) + 8 * __popc(bits & 0xAAAAu & 0xF0F0u);
+    r2 += 16 * __popc(bits & 0xAAAAu & 0xFF00u) + 16 * __popc(bits & 0xCCCCu & 0xF0F0u);
+    r2 += 32 * __popc(bits & 0xCCCCu & 0xFF00u) + 64 * __popc(bits & 0xF0F0u & 0xFF00u);
+}
 
 template <int MODE, bool CONTOUR, bool ALIGNED>
-__global__ __launch_bounds__(FX_BLOCK) void hu_band_kernel(HuArgs A)
+__global__ __launch_bounds__(FX_BLOCK) void hu_band_kernel(HuArgs A, BandScratch G)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     u64 *red = reinterpret_cast<u64 *>(lds_raw);
-    double *bcast = reinterpret_cast<double *>(lds_raw + LDS_RED_BYTES);
-    uint32_t *hist = reinterpret_cast<uint32_t *>(lds_raw + LDS_RED_BYTES + LDS_BCAST_BYTES);
-    uint32_t *qlen = reinterpret_cast<uint32_t *>(lds_raw + BAND_LDS_COUNTERS);
     uint16_t *edge_top = reinterpret_cast<uint16_t *>(lds_raw + BAND_LDS_EDGES);
     uint16_t *edge_bot = edge_top + FX_BLOCK;
     uint32_t *queue = reinterpret_cast<uint32_t *>(lds_raw + BAND_LDS_EDGES + 4 * FX_BLOCK);
@@ -584,14 +620,6 @@ __global__ __launch_bounds__(FX_BLOCK) void hu_band_kernel(HuArgs A)
     const int ya = band * hb;
     const int x0 = tx * 16;
     const uint32_t kthr = (uint32_t)(255 - (A.thresh < 0 ? 127 : A.thresh)) * 0x00010001u;
-
-    if (CONTOUR) {
-        if (t < 64)
-            hist[t] = 0;
-        if (t == 0)
-            qlen[0] = 0;
-        __syncthreads();
-    }
 
     const bool full = ALIGNED && (x0 + 16 <= W);
     auto load_chunk = [&](int r) -> uint4 {
@@ -613,36 +641,77 @@ __global__ __launch_bounds__(FX_BLOCK) void hu_band_kernel(HuArgs A)
         return v;
     };
 
-    // Contour pixels of one row of the band: foreground with a 4-neighbour
-    // that is background.  Must be called by every lane of the wave.
-    auto detect = [&](int r, uint32_t up, uint32_t cur, uint32_t dn) {
-        const uint32_t lc = (uint32_t)__shfl_up((int)cur, 1, FX_WAVE);
-        const uint32_t rc = (uint32_t)__shfl_down((int)cur, 1, FX_WAVE);
-        const uint32_t lbit = tx > 0 ? (lc >> 15) & 1u : 0u;
-        const uint32_t rbit = tx < cpr - 1 ? (rc & 1u) : 0u;
+    // ---- contour segments -----------------------------------------------------
+    // Each wave appends to its own quarter of the LDS queue; the slot of a lane
+    // comes from a ballot, so no atomic is needed.
+    const int wcap = A.qcap >> 2;
+    uint32_t *wq = queue + wave * wcap;
+    uint32_t wn = 0;  // wave-uniform: segments this wave has queued (may run past wcap: overflow)
+    auto push = [&](int r, uint32_t bits) {
+        const unsigned long long m = __ballot(bits != 0);
+        if (m) {
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            const uint32_t idx = wn + below;
+            if (bits && idx < (uint32_t)wcap)
+                wq[idx] = bits | ((uint32_t)(((ya + r) << 6) | tx) << 16);
+            wn += (uint32_t)__popcll(m);
+        }
+    };
+    const bool has_left = tx > 0, has_right = tx < cpr - 1;
+
+    // Contour pixels (foreground with a 4-neighbour that is background) of four
+    // consecutive rows rp .. rp+3 held as two packed pairs P0 = row rp | row
+    // rp+1 << 16, P1 likewise; above = row rp-1, below = row rp+4.  Rows 0 and
+    // hb-1 of the band are left out here: their outer neighbour row belongs to
+    // another band.  Must be called by every lane of the wave.
+    auto detect4 = [&](int rp, uint32_t above, uint32_t P0, uint32_t P1, uint32_t below) {
+        const uint32_t up0 = (P0 << 16) | above;
+        const uint32_t dn0 = (P0 >> 16) | (P1 << 16);
+        const uint32_t up1 = (P1 << 16) | (P0 >> 16);
+        const uint32_t dn1 = (P1 >> 16) | (below << 16);
+        // bit 0 and bit 15 of the four rows in one word: rows rp, rp+1 at bits
+        // 0/15 and 16/31, rows rp+2, rp+3 rotated left by two
+        const uint32_t K = 0x80018001u;
+        const uint32_t p1k = P1 & K;
+        const uint32_t E = (P0 & K) | ((p1k << 2) | (p1k >> 30));
+        uint32_t EL = __builtin_amdgcn_update_dpp(0u, E, 0x138, 0xf, 0xf, false);  // wave_shr:1: from lane - 1
+        uint32_t ER = __builtin_amdgcn_update_dpp(0u, E, 0x130, 0xf, 0xf, false);  // wave_shl:1: from lane + 1
+        EL = has_left ? EL : 0u;
+        ER = has_right ? ER : 0u;
+        const uint32_t lb0 = (EL >> 15) & 0x00010001u;
+        const uint32_t lb1 = ((EL >> 17) | (EL << 15)) & 0x00010001u;
+        const uint32_t rb0 = (ER << 15) & 0x80008000u;
+        const uint32_t rb1 = (ER << 13) & 0x80008000u;
+        const uint32_t left0 = ((P0 << 1) & 0xFFFEFFFEu) | lb0, right0 = ((P0 >> 1) & 0x7FFF7FFFu) | rb0;
+        const uint32_t left1 = ((P1 << 1) & 0xFFFEFFFEu) | lb1, right1 = ((P1 >> 1) & 0x7FFF7FFFu) | rb1;
+        const uint32_t B0 = P0 & ~(up0 & dn0 & left0 & right0);
+        const uint32_t B1 = P1 & ~(up1 & dn1 & left1 & right1);
+        const int last = hb - 1;
+        if (rp > 0 && rp < last)
+            push(rp, B0 & 0xFFFFu);
+        if (rp + 1 < last)
+            push(rp + 1, B0 >> 16);
+        if (rp + 2 < last)
+            push(rp + 2, B1 & 0xFFFFu);
+        if (rp + 3 < last)
+            push(rp + 3, B1 >> 16);
+    };
+    // One row with explicit neighbours (the band's first and last row).
+    auto detect1 = [&](int r, uint32_t up, uint32_t cur, uint32_t dn) {
+        uint32_t lc = __builtin_amdgcn_update_dpp(0u, cur, 0x138, 0xf, 0xf, false);
+        uint32_t rc = __builtin_amdgcn_update_dpp(0u, cur, 0x130, 0xf, 0xf, false);
+        const uint32_t lbit = has_left ? (lc >> 15) & 1u : 0u;
+        const uint32_t rbit = has_right ? (rc & 1u) : 0u;
         const uint32_t left = ((cur << 1) | lbit) & 0xFFFFu;
         const uint32_t right = (cur >> 1) | (rbit << 15);
-        const uint32_t bits = cur & ~(up & dn & left & right);
-        if (bits) {
-            const uint32_t idx = atomicAdd(qlen, 1u);
-            if (idx < (uint32_t)A.qcap)
-                queue[idx] = bits | ((uint32_t)((ya + r) * cpr + tx) << 16);
-        }
+        push(r, cur & ~(up & dn & left & right));
     };
 
     Tot64 T;
     T.clear();
-    uint32_t c_prev = 0, c_cur = 0, c_first = 0, c_second = 0;
-    auto contour_row = [&](int r, uint32_t c) {  // r is wave-uniform
-        if (r == 0)
-            c_first = c;
-        if (r == 1)
-            c_second = c;
-        if (r >= 2)
-            detect(r - 1, c_prev, c_cur, c);
-        c_prev = c_cur;
-        c_cur = c;
-    };
+    // detection runs one group of four rows behind the loads: it needs the
+    // first row of the next group as the row below
+    uint32_t pend0 = 0, pend1 = 0, pend_above = 0, c_first = 0, c_second = 0;
 
     for (int jb = 0; jb < hb; jb += 32) {
         Acc32 a;
@@ -660,93 +729,77 @@ __global__ __launch_bounds__(FX_BLOCK) void hu_band_kernel(HuArgs A)
             chunk_sums<MODE>(v2, kthr, j + 2, a, b2);
             chunk_sums<MODE>(v3, kthr, j + 3, a, b3);
             if (CONTOUR) {
-                contour_row(r, b0);
-                if (r + 1 < hb)
-                    contour_row(r + 1, b1);
-                if (r + 2 < hb)
-                    contour_row(r + 2, b2);
-                if (r + 3 < hb)
-                    contour_row(r + 3, b3);
+                if (r == 0) {
+                    c_first = b0;
+                    c_second = b1;
+                } else {
+                    detect4(r - 4, pend_above, pend0, pend1, b0);
+                    pend_above = pend1 >> 16;
+                }
+                pend0 = b0 | (b1 << 16);
+                pend1 = b2 | (b3 << 16);
             }
         }
         flush(a, (u64)(ya + jb), 1ull, T);
     }
 
-    u64 M[10];
+    constexpr int NV = CONTOUR ? BAND_SUMS : 10;
+    u64 V[NV];
     {
         const u64 X = (u64)x0, X2 = X * X, X3 = X2 * X;
-        M[0] = T.t00;
-        M[1] = X * T.t00 + T.t10;
-        M[2] = T.t01;
-        M[3] = X2 * T.t00 + 2 * X * T.t10 + T.t20;
-        M[4] = X * T.t01 + T.t11;
-        M[5] = T.t02;
-        M[6] = X3 * T.t00 + 3 * X2 * T.t10 + 3 * X * T.t20 + T.t30;
-        M[7] = X2 * T.t01 + 2 * X * T.t11 + T.t21;
-        M[8] = X * T.t02 + T.t12;
-        M[9] = T.t03;
+        V[0] = T.t00;
+        V[1] = X * T.t00 + T.t10;
+        V[2] = T.t01;
+        V[3] = X2 * T.t00 + 2 * X * T.t10 + T.t20;
+        V[4] = X * T.t01 + T.t11;
+        V[5] = T.t02;
+        V[6] = X3 * T.t00 + 3 * X2 * T.t10 + 3 * X * T.t20 + T.t30;
+        V[7] = X2 * T.t01 + 2 * X * T.t11 + T.t21;
+        V[8] = X * T.t02 + T.t12;
+        V[9] = T.t03;
     }
+
     if (CONTOUR) {
-        // rows 0 and hb-1 of every band still miss their neighbour row in the
-        // adjacent band: publish them
+        // the last group of four rows: nothing of this band lies below it
+        const int rp = ((hb - 1) >> 2) << 2;
+        detect4(rp, pend_above, pend0, pend1, 0u);
+        // rows 0 and hb-1 miss their neighbour row in the adjacent band:
+        // exchange them through LDS
+        const int k = hb - 1 - rp;  // position of the band's last row in the last group
+        const uint32_t c_last = k == 0 ? (pend0 & 0xFFFFu) : k == 1 ? (pend0 >> 16) : k == 2 ? (pend1 & 0xFFFFu) : (pend1 >> 16);
+        const uint32_t c_prevlast = k == 0 ? pend_above : k == 1 ? (pend0 & 0xFFFFu) : k == 2 ? (pend0 >> 16) : (pend1 & 0xFFFFu);
         edge_top[t] = (uint16_t)c_first;
-        edge_bot[t] = (uint16_t)c_cur;
-    }
-    block_sum_u64<10>(M, red);  // its barriers also publish the edge rows
-
-    if (t == 0) {
-        const u64 scale = (MODE == MODE_GRAY) ? 1ull : (u64)A.on_value;
-        double raw[10];
-#pragma unroll
-        for (int k = 0; k < 10; k++)
-            raw[k] = (double)(M[k] * scale);
-        finalize_moments(raw, A.moments24 ? A.moments24 + b * 24 : nullptr,
-                         A.hu7 ? A.hu7 + b * 7 : nullptr, A.hulog7 ? A.hulog7 + b * 7 : nullptr);
-    }
-    if (!CONTOUR)
-        return;
-
-    {
+        edge_bot[t] = (uint16_t)c_last;
+        __syncthreads();
         // the thread that holds the same columns in the band above / below
         const int above = t - cpr + ((bl == 0) ? (cpr * A.bpw - FX_WAVE) : 0);
         const int below = t + cpr + ((bl == A.bpw - 1) ? (FX_WAVE - cpr * A.bpw) : 0);
         const uint32_t up_ext = (active && band > 0) ? edge_bot[above] : 0u;
         const uint32_t dn_ext = (active && band + 1 < A.nbands) ? edge_top[below] : 0u;
         if (hb == 1) {
-            detect(0, up_ext, c_first, dn_ext);
+            detect1(0, up_ext, c_first, dn_ext);
         } else {
-            detect(0, up_ext, c_first, c_second);
-            detect(hb - 1, c_prev, c_cur, dn_ext);
+            detect1(0, up_ext, c_first, c_second);
+            detect1(hb - 1, c_prevlast, c_last, dn_ext);
         }
-    }
-    __syncthreads();
+        // The wave reads back only its own part of the queue: LDS operations of
+        // one wave complete in order, so no block barrier is needed here.
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int qn = wn > (uint32_t)wcap ? 0 : (int)wn;  // overflow: the mask kernel redoes the image
 
-    const uint32_t qn_raw = qlen[0];
-    if (A.redo && t == 0)
-        A.redo[b] = qn_raw > (uint32_t)A.qcap ? 1 : 0;
-    if (qn_raw > (uint32_t)A.qcap)
-        return;  // the mask kernel redoes this image
-    const int qn = (int)qn_raw;
-    const int nb = A.n_bins;
-    const int64_t row = b * (9 + nb);
-
-    // ---- sums over contour pixels: n, sum x, sum y, sum x^2, sum xy, sum y^2
-    u64 S[6] = {0, 0, 0, 0, 0, 0};
-    {
-        uint32_t s0 = 0, sx = 0, sy = 0, sxx = 0, sxy = 0, syy = 0;  // <= 16 entries per thread: fits 32 bits
-        for (int i = t; i < qn; i += FX_BLOCK) {
-            const uint32_t e = queue[i];
-            const uint32_t bits = e & 0xFFFFu, pos = e >> 16;
-            const uint32_t y = pos / (uint32_t)cpr, X = (pos - y * cpr) * 16u;
-            const uint32_t p0 = __popc(bits & 0xAAAAu), p1 = __popc(bits & 0xCCCCu);
-            const uint32_t p2 = __popc(bits & 0xF0F0u), p3 = __popc(bits & 0xFF00u);
-            const uint32_t r0 = __popc(bits);
-            const uint32_t r1 = p0 + 2 * p1 + 4 * p2 + 8 * p3;
-            uint32_t r2 = p0 + 4 * p1 + 16 * p2 + 64 * p3;
-            r2 += 4 * __popc(bits & 0xAAAAu & 0xCCCCu) + 8 * __popc(bits & 0xAAAAu & 0xF0F0u);
-            r2 += 16 * __popc(bits & 0xAAAAu & 0xFF00u) + 16 * __popc(bits & 0xCCCCu & 0xF0F0u);
-            r2 += 32 * __popc(bits & 0xCCCCu & 0xFF00u) + 64 * __popc(bits & 0xF0F0u & 0xFF00u);
-            const uint32_t ex = X * r0 + r1;  // sum of x over the segment
+        // sums over contour pixels: n, sum x, sum y, sum x^2, sum xy, sum y^2;
+        // at most 16 segments per lane, so 32-bit partial sums cannot overflow
+        uint32_t s0 = 0, sx = 0, sy = 0, sxx = 0, sxy = 0, syy = 0;
+        uint32_t *gq = G.queue + (b * FX_WAVES_PER_BLOCK + wave) * wcap;
+        for (int i = lane; i < qn; i += FX_WAVE) {
+            const uint32_t e = wq[i];
+            gq[i] = e;
+            const uint32_t pos = e >> 16;
+            const uint32_t y = pos >> 6, X = (pos & 63u) * 16u;
+            uint32_t r0, r1, r2;
+            segment_sums(e & 0xFFFFu, r0, r1, r2);
+            const uint32_t ex = X * r0 + r1;
             s0 += r0;
             sx += ex;
             sy += y * r0;
@@ -754,98 +807,161 @@ __global__ __launch_bounds__(FX_BLOCK) void hu_band_kernel(HuArgs A)
             sxy += y * ex;
             syy += y * y * r0;
         }
-        S[0] = s0;
-        S[1] = sx;
-        S[2] = sy;
-        S[3] = sxx;
-        S[4] = sxy;
-        S[5] = syy;
+        V[NV - 6] = s0;
+        V[NV - 5] = sx;
+        V[NV - 4] = sy;
+        V[NV - 3] = sxx;
+        V[NV - 2] = sxy;
+        V[NV - 1] = syy;
+        if (lane == 0)
+            G.qcount[b * FX_WAVES_PER_BLOCK + wave] = wn;
     }
-    block_sum_u64<6>(S, red);
+    block_sum_u64<NV>(V, red);
+    if (t == 0) {
+        u64 *out = G.sums + b * BAND_SUMS;
+#pragma unroll
+        for (int k = 0; k < NV; k++)
+            out[k] = V[k];
+    }
+}
 
-    const u64 n = S[0];
+// One lane per image: everything that is serial float64 arithmetic.
+__global__ __launch_bounds__(FX_BLOCK) void hu_finalize_kernel(HuArgs A, BandScratch G, int gray, int contour)
+{
+    const int64_t b = (int64_t)blockIdx.x * FX_BLOCK + threadIdx.x;
+    if (b >= A.B)
+        return;
+    const u64 *sums = G.sums + b * BAND_SUMS;
+    const u64 scale = gray ? 1ull : (u64)A.on_value;
+    double raw[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++)
+        raw[k] = (double)(sums[k] * scale);
+    finalize_moments(raw, A.moments24 ? A.moments24 + b * 24 : nullptr, A.hu7 ? A.hu7 + b * 7 : nullptr,
+                     A.hulog7 ? A.hulog7 + b * 7 : nullptr);
+    if (!contour || band_overflowed(G.qcount, b, A.qcap))
+        return;
+    const int nb = A.n_bins;
+    const int64_t row = b * (9 + nb);
+    const u64 n = sums[10];
     if (n < 3) {
-        const float nanv = __builtin_nanf("");
-        for (int i = t; i < 9 + nb; i += FX_BLOCK)
-            A.cpca[row + i] = nanv;
-        if (A.ceig && t < 6)
-            A.ceig[b * 6 + t] = __builtin_nan("");
+        for (int i = 0; i < 9 + nb; i++)
+            A.cpca[row + i] = __builtin_nanf("");
+        if (A.ceig)
+            for (int i = 0; i < 6; i++)
+                A.ceig[b * 6 + i] = __builtin_nan("");
         return;
     }
-    if (t == 0) {
-        const double dn = (double)n;
-        const double inv = 1.0 / (dn * (double)(n - 1));
-        const i64 sx = (i64)S[1], sy = (i64)S[2];
-        const double cxx = (double)((i64)(n * S[3]) - sx * sx) * inv;
-        const double cxy = (double)((i64)(n * S[4]) - sx * sy) * inv;
-        const double cyy = (double)((i64)(n * S[5]) - sy * sy) * inv;
-        double lam[3], v1[3], head[9];
-        fx_eig3(cxx, cxy, 0.0, cyy, 0.0, 0.0, lam, v1);
-        fx_pca_head(lam, head);
-        for (int i = 0; i < 9; i++)
-            A.cpca[row + i] = (float)head[i];
-        if (A.ceig) {
-            for (int i = 0; i < 3; i++) {
-                A.ceig[b * 6 + i] = lam[i];
-                A.ceig[b * 6 + 3 + i] = v1[i];
-            }
+    // covariance (ddof = 1) from exact integer sums: n*Sxx - Sx^2 etc.
+    const double dn = (double)n;
+    const double inv = 1.0 / (dn * (double)(n - 1));
+    const i64 sx = (i64)sums[11], sy = (i64)sums[12];
+    const double cxx = (double)((i64)(n * sums[13]) - sx * sx) * inv;
+    const double cxy = (double)((i64)(n * sums[14]) - sx * sy) * inv;
+    const double cyy = (double)((i64)(n * sums[15]) - sy * sy) * inv;
+    double lam[3], v1[3], head[9];
+    fx_eig3(cxx, cxy, 0.0, cyy, 0.0, 0.0, lam, v1);
+    fx_pca_head(lam, head);
+    for (int i = 0; i < 9; i++)
+        A.cpca[row + i] = (float)head[i];
+    if (A.ceig) {
+        for (int i = 0; i < 3; i++) {
+            A.ceig[b * 6 + i] = lam[i];
+            A.ceig[b * 6 + 3 + i] = v1[i];
         }
-        bcast[0] = (double)S[1] / dn;
-        bcast[1] = (double)S[2] / dn;
-        bcast[2] = v1[0];
-        bcast[3] = v1[1];
     }
-    __syncthreads();
-    const double ccx = bcast[0], ccy = bcast[1], vx = bcast[2], vy = bcast[3];
+    double *p = G.params + b * 4;
+    p[0] = (double)sx / dn;
+    p[1] = (double)sy / dn;
+    p[2] = v1[0];
+    p[3] = v1[1];
+}
 
-    // signed projection of pixel (X + i, y); monotone in i
+// One wave per image: largest |projection on PC1| over the contour pixels and
+// the histogram of it, from the queued segments.  Along a segment the signed
+// projection is monotone in x, so its largest magnitude is at an end, and a
+// segment whose two ends fall into the same bin on the same side of zero
+// belongs to that bin as a whole.
+__global__ __launch_bounds__(FX_BLOCK) void hu_contour_hist_kernel(HuArgs A, BandScratch G)
+{
+    __shared__ uint32_t hist_all[FX_WAVES_PER_BLOCK][64];
+    const int lane = fx_lane(), wave = fx_wave();
+    const int64_t b = (int64_t)blockIdx.x * FX_WAVES_PER_BLOCK + wave;
+    if (b >= A.B)
+        return;  // waves are independent: no block barrier below
+    const u64 n = G.sums[b * BAND_SUMS + 10];
+    if (band_overflowed(G.qcount, b, A.qcap) || n < 3)
+        return;
+    const int wcap = A.qcap >> 2;
+    const uint32_t *qc = G.qcount + b * FX_WAVES_PER_BLOCK;
+    const int c0 = (int)qc[0], c1 = c0 + (int)qc[1], c2 = c1 + (int)qc[2], qn = c2 + (int)qc[3];
+    const int nb = A.n_bins;
+    uint32_t *hist = hist_all[wave];
+    hist[lane] = 0;
+    const double *p = G.params + b * 4;
+    const double ccx = p[0], ccy = p[1], vx = p[2], vy = p[3];
+    const uint32_t *gq = G.queue + b * FX_WAVES_PER_BLOCK * wcap;
+    // segment i of the image: the four per-wave parts one after the other
+    auto segment = [&](int i) -> uint32_t {
+        const int part = (i >= c0) + (i >= c1) + (i >= c2);
+        const int first = part == 0 ? 0 : part == 1 ? c0 : part == 2 ? c1 : c2;
+        return gq[part * wcap + (i - first)];
+    };
+
     auto sproj = [&](uint32_t X, int i, double dyv) -> double {
         return fma(dyv, vy, ((double)(int)(X + i) - ccx) * vx);
     };
 
-    // ---- largest |projection|: at an end of each segment --------------------
     double top = 0.0;
-    for (int i = t; i < qn; i += FX_BLOCK) {
-        const uint32_t e = queue[i];
+    for (int i = lane; i < qn; i += FX_WAVE) {
+        const uint32_t e = segment(i);
         const uint32_t bits = e & 0xFFFFu, pos = e >> 16;
-        const uint32_t y = pos / (uint32_t)cpr, X = (pos - y * cpr) * 16u;
+        const uint32_t y = pos >> 6, X = (pos & 63u) * 16u;
         const double dy = (double)(int)y - ccy;
         const int lo = __ffs((int)bits) - 1, hi = 31 - __clz((int)bits);
         top = fmax(top, fmax(fabs(sproj(X, lo, dy)), fabs(sproj(X, hi, dy))));
     }
-    top = block_max_f64(top, reinterpret_cast<double *>(red));
+    top = fx_wave_max_f64(top);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 
-    if (top > 0.0) {
-        const double step = top / (double)nb;
-        const double inv_step = (double)nb / top;
-        for (int i = t; i < qn; i += FX_BLOCK) {
-            const uint32_t e = queue[i];
-            const uint32_t bits = e & 0xFFFFu, pos = e >> 16;
-            const uint32_t y = pos / (uint32_t)cpr, X = (pos - y * cpr) * 16u;
-            const double dy = (double)(int)y - ccy;
-            int lo = __ffs((int)bits) - 1;
-            const int hi = 31 - __clz((int)bits);
-            const double slo = sproj(X, lo, dy), shi = sproj(X, hi, dy);
-            int blo = fx_hist_bin(fabs(slo), step, inv_step, nb);
-            const int bhi = fx_hist_bin(fabs(shi), step, inv_step, nb);
-            if (blo == bhi && ((slo < 0.0) == (shi < 0.0))) {
-                // |projection| is monotone between the two ends: one bin for the segment
-                atomicAdd(&hist[blo], (uint32_t)__popc(bits));
-            } else {
-                uint32_t rest = bits;
-                while (rest) {
-                    const int k = __ffs((int)rest) - 1;
-                    rest &= rest - 1;
-                    atomicAdd(&hist[fx_hist_bin(fabs(sproj(X, k, dy)), step, inv_step, nb)], 1u);
-                }
+    float *out = A.cpca + b * (9 + nb) + 9;
+    if (!(top > 0.0)) {
+        if (lane < nb)
+            out[lane] = lane == 0 ? 1.0f : 0.0f;
+        return;
+    }
+    const double step = top / (double)nb;
+    const double inv_step = (double)nb / top;
+    for (int i = lane; i < qn; i += FX_WAVE) {
+        const uint32_t e = segment(i);
+        const uint32_t bits = e & 0xFFFFu, pos = e >> 16;
+        const uint32_t y = pos >> 6, X = (pos & 63u) * 16u;
+        const double dy = (double)(int)y - ccy;
+        const int lo = __ffs((int)bits) - 1, hi = 31 - __clz((int)bits);
+        const double slo = sproj(X, lo, dy);
+        const int blo = fx_hist_bin(fabs(slo), step, inv_step, nb);
+        if (lo == hi) {
+            atomicAdd(&hist[blo], 1u);
+            continue;
+        }
+        const double shi = sproj(X, hi, dy);
+        const int bhi = fx_hist_bin(fabs(shi), step, inv_step, nb);
+        if (blo == bhi && ((slo < 0.0) == (shi < 0.0))) {
+            atomicAdd(&hist[blo], (uint32_t)__popc(bits));
+        } else {
+            uint32_t rest = bits;
+            while (rest) {
+                const int k = __ffs((int)rest) - 1;
+                rest &= rest - 1;
+                atomicAdd(&hist[fx_hist_bin(fabs(sproj(X, k, dy)), step, inv_step, nb)], 1u);
             }
         }
-        __syncthreads();
-        if (t < nb)
-            A.cpca[row + 9 + t] = (float)((double)hist[t] / (double)n);
-    } else if (t < nb) {
-        A.cpca[row + 9 + t] = t == 0 ? 1.0f : 0.0f;
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < nb)
+        out[lane] = (float)((double)hist[lane] / (double)n);
 }
 
 __global__ void hu_groupstat_kernel(const float *hulog7, const int64_t *offsets, int64_t G, float *out14)
@@ -890,31 +1006,37 @@ int launch_image_kernel(const HuArgs &A, bool aligned, size_t lds, hipStream_t s
 }
 
 template <int MODE, bool CONTOUR>
-int launch_band_kernel(const HuArgs &A, bool aligned, size_t lds, hipStream_t s)
+int launch_band_kernel(const HuArgs &A, const BandScratch &G, bool aligned, size_t lds, hipStream_t s)
 {
     dim3 grid((unsigned)A.B), block(FX_BLOCK);
     if (aligned)
-        hipLaunchKernelGGL((hu_band_kernel<MODE, CONTOUR, true>), grid, block, lds, s, A);
+        hipLaunchKernelGGL((hu_band_kernel<MODE, CONTOUR, true>), grid, block, lds, s, A, G);
     else
-        hipLaunchKernelGGL((hu_band_kernel<MODE, CONTOUR, false>), grid, block, lds, s, A);
+        hipLaunchKernelGGL((hu_band_kernel<MODE, CONTOUR, false>), grid, block, lds, s, A, G);
     FX_HIP_CHECK(hipGetLastError());
     return FX_OK;
 }
 
-template <bool BAND>
-int launch_hu(const HuArgs &A, int mode, bool contour, bool aligned, size_t lds, hipStream_t s)
+int launch_band(const HuArgs &A, const BandScratch &G, int mode, bool contour, bool aligned, size_t lds, hipStream_t s)
 {
-#define FX_PICK(FN)                                                                        \
-    (contour ? (mode == MODE_GRAY   ? FN<MODE_GRAY, true>(A, aligned, lds, s)              \
-                : mode == MODE_BIT7 ? FN<MODE_BIT7, true>(A, aligned, lds, s)              \
-                                    : FN<MODE_THRESH, true>(A, aligned, lds, s))           \
-             : (mode == MODE_GRAY   ? FN<MODE_GRAY, false>(A, aligned, lds, s)             \
-                : mode == MODE_BIT7 ? FN<MODE_BIT7, false>(A, aligned, lds, s)             \
-                                    : FN<MODE_THRESH, false>(A, aligned, lds, s)))
-    if (BAND)
-        return FX_PICK(launch_band_kernel);
-    return FX_PICK(launch_image_kernel);
-#undef FX_PICK
+    if (contour)
+        return mode == MODE_GRAY   ? launch_band_kernel<MODE_GRAY, true>(A, G, aligned, lds, s)
+               : mode == MODE_BIT7 ? launch_band_kernel<MODE_BIT7, true>(A, G, aligned, lds, s)
+                                   : launch_band_kernel<MODE_THRESH, true>(A, G, aligned, lds, s);
+    return mode == MODE_GRAY   ? launch_band_kernel<MODE_GRAY, false>(A, G, aligned, lds, s)
+           : mode == MODE_BIT7 ? launch_band_kernel<MODE_BIT7, false>(A, G, aligned, lds, s)
+                               : launch_band_kernel<MODE_THRESH, false>(A, G, aligned, lds, s);
+}
+
+int launch_mask(const HuArgs &A, int mode, bool contour, bool aligned, size_t lds, hipStream_t s)
+{
+    if (contour)
+        return mode == MODE_GRAY   ? launch_image_kernel<MODE_GRAY, true>(A, aligned, lds, s)
+               : mode == MODE_BIT7 ? launch_image_kernel<MODE_BIT7, true>(A, aligned, lds, s)
+                                   : launch_image_kernel<MODE_THRESH, true>(A, aligned, lds, s);
+    return mode == MODE_GRAY   ? launch_image_kernel<MODE_GRAY, false>(A, aligned, lds, s)
+           : mode == MODE_BIT7 ? launch_image_kernel<MODE_BIT7, false>(A, aligned, lds, s)
+                               : launch_image_kernel<MODE_THRESH, false>(A, aligned, lds, s);
 }
 
 }  // namespace
@@ -973,34 +1095,63 @@ extern "C" int fx_hu_batch_u8(const uint8_t *d_img, int64_t B, int H, int W, int
     const size_t mask_lds = LDS_HEAD_BYTES + mask_bytes;
     const int mode = thresh < 0 ? MODE_GRAY : (thresh == 127 ? MODE_BIT7 : MODE_THRESH);
 
-    // Band kernel: a row must fit in one wave and a queue position in 16 bits.
-    bool band = A.cpr <= FX_WAVE && (int64_t)H * A.cpr <= 65536;
-    const char *force = getenv("FX_HU_KERNEL");  // "mask" or "band": development switch
+    // Band kernel: a row must fit in one wave and a queue position (row, chunk)
+    // in 10 + 6 bits.
+    bool band = A.cpr <= FX_WAVE && H <= 1024;
+    const char *force = getenv("FX_HU_KERNEL");  // "mask": development switch
     if (force && strcmp(force, "mask") == 0)
         band = false;
-    A.bpw = band ? FX_WAVE / A.cpr : 0;
-    A.nbands = A.bpw * FX_WAVES_PER_BLOCK;
-    A.hb = band ? (H + A.nbands - 1) / A.nbands : 0;
-    const int64_t segments = (int64_t)H * A.cpr;
-    A.qcap = (int)(segments < 4096 ? segments : 4096);
 
-    FxProfileScope prof(s);
-    if (!band)
-        return launch_hu<false>(A, mode, contour, aligned, mask_lds, s);
-
-    const bool may_overflow = contour && A.qcap < segments;
-    if (may_overflow) {
-        A.redo = (uint8_t *)fx_scratch((size_t)B, 1);
-        if (!A.redo)
-            return FX_ENOMEM;
+    // launch timing (when switched on) brackets the streaming kernel only
+    if (!band) {
+        FxProfileScope prof(s);
+        return launch_mask(A, mode, contour, aligned, mask_lds, s);
     }
+
+    A.bpw = FX_WAVE / A.cpr;
+    A.nbands = A.bpw * FX_WAVES_PER_BLOCK;
+    A.hb = (H + A.nbands - 1) / A.nbands;
+    // every wave could meet all segments of its bands: cap per wave, four waves
+    const int64_t wave_segments = (int64_t)A.hb * A.bpw * A.cpr;
+    A.qcap = (int)(wave_segments < 1024 ? wave_segments : 1024) * FX_WAVES_PER_BLOCK;
+
+    // per-launch scratch: sums | queue counts | contour parameters | queues
+    const size_t sums_bytes = (size_t)B * BAND_SUMS * sizeof(u64);
+    const size_t count_bytes = (size_t)B * FX_WAVES_PER_BLOCK * 4;
+    const size_t param_bytes = contour ? (size_t)B * 4 * sizeof(double) : 0;
+    const size_t queue_bytes = contour ? (size_t)B * A.qcap * 4 : 0;
+    unsigned char *base = (unsigned char *)fx_scratch(sums_bytes + count_bytes + param_bytes + queue_bytes, 1);
+    if (!base)
+        return FX_ENOMEM;
+    BandScratch G;
+    G.sums = (u64 *)base;
+    G.qcount = (uint32_t *)(base + sums_bytes);
+    G.params = (double *)(base + sums_bytes + count_bytes);
+    G.queue = (uint32_t *)(base + sums_bytes + count_bytes + param_bytes);
+
     const size_t band_lds = contour ? (size_t)BAND_LDS_EDGES + 4 * FX_BLOCK + (size_t)A.qcap * 4 : (size_t)LDS_HEAD_BYTES;
-    int rc = launch_hu<true>(A, mode, contour, aligned, band_lds, s);
-    if (rc != FX_OK || !may_overflow)
+    int rc;
+    {
+        FxProfileScope prof(s);
+        rc = launch_band(A, G, mode, contour, aligned, band_lds, s);
+    }
+    if (rc != FX_OK)
         return rc;
-    // images whose contour queue overflowed (very ragged masks) go through the mask kernel
-    A.only_redo = 1;
-    return launch_hu<false>(A, mode, contour, aligned, mask_lds, s);
+    hipLaunchKernelGGL(hu_finalize_kernel, dim3((unsigned)((B + FX_BLOCK - 1) / FX_BLOCK)), dim3(FX_BLOCK), 0, s, A, G,
+                       mode == MODE_GRAY ? 1 : 0, contour ? 1 : 0);
+    FX_HIP_CHECK(hipGetLastError());
+    if (!contour)
+        return FX_OK;
+    hipLaunchKernelGGL(hu_contour_hist_kernel, dim3((unsigned)((B + FX_WAVES_PER_BLOCK - 1) / FX_WAVES_PER_BLOCK)),
+                       dim3(FX_BLOCK), 0, s, A, G);
+    FX_HIP_CHECK(hipGetLastError());
+    if ((A.qcap >> 2) < wave_segments) {
+        // images whose contour queue overflowed (very ragged masks) go through the mask kernel
+        A.redo = G.qcount;
+        A.only_redo = 1;
+        return launch_mask(A, mode, contour, aligned, mask_lds, s);
+    }
+    return FX_OK;
 }
 
 extern "C" int fx_hu_groupstat(const float *d_hulog7, const int64_t *d_group_offsets, int64_t G, float *d_out14,
