@@ -43,13 +43,12 @@ struct HuArgs {
     // band kernel: each wave holds bpw bands of cpr lanes; a band is hb
     // consecutive rows; qcap entries fit in the contour queue
     int bpw, nbands, hb, qcap;
-    // segments the band kernel found per image; above qcap its queue
-    // overflowed and the mask kernel has to redo the image
-    const uint32_t *redo;
-    int only_redo;  // mask kernel: skip images that did not overflow
+    int wave_lds;  // bytes of LDS per wave: its queue part, at least the 4 KiB reduction slab
+    // images whose band-kernel contour queue overflowed; the mask kernel redoes them
+    const uint32_t *redo_count;
+    const uint32_t *redo_list;
+    int only_redo;  // mask kernel: work through redo_list instead of all B images
 };
-
-__device__ __forceinline__ bool band_overflowed(const uint32_t *qcount, int64_t b, int qcap);
 
 constexpr int MODE_GRAY = 0;     // weight = pixel value
 constexpr int MODE_BIT7 = 1;     // weight = on_value * (pixel > 127)
@@ -89,8 +88,9 @@ __device__ __forceinline__ uint32_t gt_bytes(uint32_t a, uint32_t k)
     return ((e >> 8) & 0x00010001u) | (o & 0x01000100u);
 }
 
-// Per-lane 32-bit partial sums over up to 32 visited rows j = 0..31 of the
-// strip: a[k][q] = sum_j j^q * s_k(j), s_k = sum_i i^k * w_i over the chunk.
+// Per-lane 32-bit partial sums over the visited rows j = 0, 1, ... of the strip
+// (up to 32 rows with gray weights, 128 with 0/1 weights):
+// a[k][q] = sum_j j^q * s_k(j), s_k = sum_i i^k * w_i over the chunk.
 struct Acc32 {
     uint32_t a00, a10, a20, a30, a01, a11, a21, a02, a12, a03;
     __device__ __forceinline__ void clear() { a00 = a10 = a20 = a30 = a01 = a11 = a21 = a02 = a12 = a03 = 0; }
@@ -133,7 +133,7 @@ __device__ __forceinline__ void chunk_sums(const uint4 &v, uint32_t kthr, uint32
         s3h = dot4(src[d], K3H(d), s3h);
     }
     uint32_t s3 = s3l + (s3h << 8);
-    uint32_t j2 = j * j, j3 = j2 * j;  // j < 32, wave-uniform
+    uint32_t j2 = j * j, j3 = j2 * j;  // j < 128, wave-uniform
     a.a00 += s0;
     a.a10 += s1;
     a.a20 += s2;
@@ -311,18 +311,14 @@ constexpr int LDS_HIST_BYTES = 256;   // 64 x u32 histogram
 constexpr int LDS_HEAD_BYTES = LDS_RED_BYTES + LDS_BCAST_BYTES + LDS_HIST_BYTES;
 
 template <int MODE, bool CONTOUR, bool ALIGNED>
-__global__ __launch_bounds__(FX_BLOCK) void hu_image_kernel(HuArgs A)
+__device__ __forceinline__ void hu_image_body(const HuArgs &A, const int64_t b, unsigned char *lds_raw)
 {
-    extern __shared__ __align__(16) unsigned char lds_raw[];
     u64 *red = reinterpret_cast<u64 *>(lds_raw);
     double *bcast = reinterpret_cast<double *>(lds_raw + LDS_RED_BYTES);
     uint32_t *hist = reinterpret_cast<uint32_t *>(lds_raw + LDS_RED_BYTES + LDS_BCAST_BYTES);
     uint32_t *mask = reinterpret_cast<uint32_t *>(lds_raw + LDS_HEAD_BYTES);
 
     const int t = threadIdx.x;
-    const int64_t b = blockIdx.x;
-    if (A.only_redo && !band_overflowed(A.redo, b, A.qcap))
-        return;
     const uint8_t *img = A.img + b * A.stride;
     const int H = A.H, W = A.W;
 
@@ -551,6 +547,19 @@ __global__ __launch_bounds__(FX_BLOCK) void hu_image_kernel(HuArgs A)
 }
 
 
+// One block per image; in redo mode a small grid walks the list of images whose
+// band-kernel contour queue overflowed (the list is filled by hu_finalize_kernel).
+template <int MODE, bool CONTOUR, bool ALIGNED>
+__global__ __launch_bounds__(FX_BLOCK) void hu_image_kernel(HuArgs A)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int64_t items = A.only_redo ? (int64_t)A.redo_count[0] : A.B;
+    for (int64_t it = blockIdx.x; it < items; it += gridDim.x) {
+        hu_image_body<MODE, CONTOUR, ALIGNED>(A, A.only_redo ? (int64_t)A.redo_list[it] : it, lds_raw);
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------ band kernel
 // Organisation for images up to 1024 x 1024.  A row of the image (cpr chunks)
 // sits in cpr adjacent lanes of one wave; each group of cpr lanes owns a band
@@ -569,6 +578,10 @@ __global__ __launch_bounds__(FX_BLOCK) void hu_image_kernel(HuArgs A)
 // histogram over the queued segments).
 constexpr int BAND_LDS_COUNTERS = LDS_HEAD_BYTES;          // 16 B: queue length
 constexpr int BAND_LDS_EDGES = BAND_LDS_COUNTERS + 16;     // top/bottom row masks of every band
+// per-wave region: first the wave's part of the segment queue, later (the queue
+// has been consumed by then) the 4 KiB slab of the wave-level reduction
+constexpr int BAND_LDS_WAVE = BAND_LDS_EDGES + 4 * FX_BLOCK;
+constexpr int BAND_SLAB_BYTES = 4096;
 constexpr int BAND_SUMS = 16;                              // u64 per image: 10 raw moments + 6 contour sums
 
 struct BandScratch {
@@ -576,6 +589,8 @@ struct BandScratch {
     uint32_t *qcount;  // [B][4] segments each wave found (above qcap / 4: the mask kernel redoes the image)
     uint32_t *queue;   // [B][4][qcap / 4] segment = 16-pixel mask | (y << 6 | chunk) << 16
     double *params;    // [B][4] contour centroid x, y and first principal axis x, y
+    uint32_t *redo_count;  // [1] zeroed before the launches
+    uint32_t *redo_list;   // [B] images for the mask kernel
 };
 
 __device__ __forceinline__ bool band_overflowed(const uint32_t *qcount, int64_t b, int qcap)
@@ -599,14 +614,17 @@ __device__ __forceinline__ void segment_sums(uint32_t bits, uint32_t &r0, uint32
     r2 += 32 * __popc(bits & 0xCCCCu & 0xFF00u) + 64 * __popc(bits & 0xF0F0u & 0xFF00u);
 }
 
+#ifndef FX_BAND_WAVES
+#define FX_BAND_WAVES 4
+#endif
 template <int MODE, bool CONTOUR, bool ALIGNED>
-__global__ __launch_bounds__(FX_BLOCK) void hu_band_kernel(HuArgs A, BandScratch G)
+__global__ __launch_bounds__(FX_BLOCK, FX_BAND_WAVES) void hu_band_kernel(HuArgs A, BandScratch G)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     u64 *red = reinterpret_cast<u64 *>(lds_raw);
     uint16_t *edge_top = reinterpret_cast<uint16_t *>(lds_raw + BAND_LDS_EDGES);
     uint16_t *edge_bot = edge_top + FX_BLOCK;
-    uint32_t *queue = reinterpret_cast<uint32_t *>(lds_raw + BAND_LDS_EDGES + 4 * FX_BLOCK);
+    const int wave_bytes = A.wave_lds;  // >= BAND_SLAB_BYTES
 
     const int t = threadIdx.x;
     const int lane = fx_lane(), wave = fx_wave();
@@ -621,22 +639,32 @@ __global__ __launch_bounds__(FX_BLOCK) void hu_band_kernel(HuArgs A, BandScratch
     const int x0 = tx * 16;
     const uint32_t kthr = (uint32_t)(255 - (A.thresh < 0 ? 127 : A.thresh)) * 0x00010001u;
 
-    const bool full = ALIGNED && (x0 + 16 <= W);
+    // ALIGNED: every chunk is a whole, 16-byte aligned vector.  The load is then
+    // unconditional (rows outside the band or the image read a clamped address
+    // and are zeroed afterwards), which lets the four loads of a group issue
+    // back to back.
     auto load_chunk = [&](int r) -> uint4 {
-        uint4 v = make_uint4(0, 0, 0, 0);
         const int y = ya + r;
-        if (active && r < hb && y < H) {
+        const bool valid = active && r < hb && y < H;
+        if (ALIGNED) {
+            const int yc = valid ? y : 0;
+            const int xc = active ? x0 : 0;
+            uint4 v = *reinterpret_cast<const uint4 *>(img + (int64_t)yc * A.pitch + xc);
+            v.x = valid ? v.x : 0u;
+            v.y = valid ? v.y : 0u;
+            v.z = valid ? v.z : 0u;
+            v.w = valid ? v.w : 0u;
+            return v;
+        }
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (valid) {
             const uint8_t *p = img + (int64_t)y * A.pitch + x0;
-            if (full) {
-                v = *reinterpret_cast<const uint4 *>(p);
-            } else {
-                uint32_t w[4] = {0, 0, 0, 0};
-                int n = W - x0;
-                n = n > 16 ? 16 : n;
-                for (int k = 0; k < n; k++)
-                    w[k >> 2] |= (uint32_t)p[k] << (8 * (k & 3));
-                v = make_uint4(w[0], w[1], w[2], w[3]);
-            }
+            uint32_t w[4] = {0, 0, 0, 0};
+            int n = W - x0;
+            n = n > 16 ? 16 : n;
+            for (int k = 0; k < n; k++)
+                w[k >> 2] |= (uint32_t)p[k] << (8 * (k & 3));
+            v = make_uint4(w[0], w[1], w[2], w[3]);
         }
         return v;
     };
@@ -645,7 +673,7 @@ __global__ __launch_bounds__(FX_BLOCK) void hu_band_kernel(HuArgs A, BandScratch
     // Each wave appends to its own quarter of the LDS queue; the slot of a lane
     // comes from a ballot, so no atomic is needed.
     const int wcap = A.qcap >> 2;
-    uint32_t *wq = queue + wave * wcap;
+    uint32_t *wq = reinterpret_cast<uint32_t *>(lds_raw + BAND_LDS_WAVE + wave * wave_bytes);
     uint32_t wn = 0;  // wave-uniform: segments this wave has queued (may run past wcap: overflow)
     auto push = [&](int r, uint32_t bits) {
         const unsigned long long m = __ballot(bits != 0);
@@ -713,11 +741,14 @@ __global__ __launch_bounds__(FX_BLOCK) void hu_band_kernel(HuArgs A, BandScratch
     // first row of the next group as the row below
     uint32_t pend0 = 0, pend1 = 0, pend_above = 0, c_first = 0, c_second = 0;
 
-    for (int jb = 0; jb < hb; jb += 32) {
-        Acc32 a;
-        a.clear();
+    // Rows per flush of the 32-bit partial sums.  With 0/1 weights (binary
+    // modes) they are 255 times smaller than with gray weights and can run over
+    // 128 rows: for bands up to that height the 64-bit totals are formed once,
+    // after the loop, and are not live inside it.
+    constexpr int SUB = (MODE == MODE_GRAY) ? 32 : 128;
+    auto run_rows = [&](int jb, Acc32 &a) {
 #pragma unroll 1
-        for (int j = 0; j < 32 && jb + j < hb; j += 4) {
+        for (int j = 0; j < SUB && jb + j < hb; j += 4) {
             const int r = jb + j;
             uint4 v0 = load_chunk(r);
             uint4 v1 = load_chunk(r + 1);
@@ -740,7 +771,19 @@ __global__ __launch_bounds__(FX_BLOCK) void hu_band_kernel(HuArgs A, BandScratch
                 pend1 = b2 | (b3 << 16);
             }
         }
-        flush(a, (u64)(ya + jb), 1ull, T);
+    };
+    if (hb <= SUB) {
+        Acc32 a;
+        a.clear();
+        run_rows(0, a);
+        flush(a, (u64)ya, 1ull, T);
+    } else {
+        for (int jb = 0; jb < hb; jb += SUB) {
+            Acc32 a;
+            a.clear();
+            run_rows(jb, a);
+            flush(a, (u64)(ya + jb), 1ull, T);
+        }
     }
 
     constexpr int NV = CONTOUR ? BAND_SUMS : 10;
@@ -816,12 +859,44 @@ __global__ __launch_bounds__(FX_BLOCK) void hu_band_kernel(HuArgs A, BandScratch
         if (lane == 0)
             G.qcount[b * FX_WAVES_PER_BLOCK + wave] = wn;
     }
-    block_sum_u64<NV>(V, red);
-    if (t == 0) {
-        u64 *out = G.sums + b * BAND_SUMS;
+    // ---- block sums ---------------------------------------------------------------
+    // Wave level: the lanes park eight values at a time in the wave's 4 KiB LDS
+    // slab as [value][lane]; lane l then adds the eight lanes 8*(l&7).. of value
+    // l>>3 and three butterfly steps finish the 64-lane sum.  (16 LDS accesses
+    // and 6 cross-lane moves per lane instead of 12 cross-lane moves per value.)
+    u64 *slab = reinterpret_cast<u64 *>(lds_raw + BAND_LDS_WAVE + wave * wave_bytes);
+    u64 wsum[2] = {0, 0};  // lane l: wave total of value l>>3 (pass 0) and 8 + (l>>3) (pass 1)
 #pragma unroll
-        for (int k = 0; k < NV; k++)
-            out[k] = V[k];
+    for (int pass = 0; pass < (NV + 7) / 8; pass++) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            slab[k * FX_WAVE + lane] = (pass * 8 + k < NV) ? V[(pass * 8 + k < NV) ? pass * 8 + k : 0] : 0ull;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        u64 acc = 0;
+        const u64 *col = slab + (lane >> 3) * FX_WAVE + (lane & 7) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            acc += col[i];
+        acc += (u64)__shfl_xor((unsigned long long)acc, 1, FX_WAVE);
+        acc += (u64)__shfl_xor((unsigned long long)acc, 2, FX_WAVE);
+        acc += (u64)__shfl_xor((unsigned long long)acc, 4, FX_WAVE);
+        wsum[pass] = acc;
+    }
+    // Block level: 4 waves x 16 values through `red`.
+    if ((lane & 7) == 0) {
+        red[wave * BAND_SUMS + (lane >> 3)] = wsum[0];
+        red[wave * BAND_SUMS + 8 + (lane >> 3)] = wsum[1];
+    }
+    __syncthreads();
+    if (t < NV) {
+        u64 sum = 0;
+#pragma unroll
+        for (int w = 0; w < FX_WAVES_PER_BLOCK; w++)
+            sum += red[w * BAND_SUMS + t];
+        G.sums[b * BAND_SUMS + t] = sum;
     }
 }
 
@@ -839,8 +914,12 @@ __global__ __launch_bounds__(FX_BLOCK) void hu_finalize_kernel(HuArgs A, BandScr
         raw[k] = (double)(sums[k] * scale);
     finalize_moments(raw, A.moments24 ? A.moments24 + b * 24 : nullptr, A.hu7 ? A.hu7 + b * 7 : nullptr,
                      A.hulog7 ? A.hulog7 + b * 7 : nullptr);
-    if (!contour || band_overflowed(G.qcount, b, A.qcap))
+    if (!contour)
         return;
+    if (band_overflowed(G.qcount, b, A.qcap)) {
+        G.redo_list[atomicAdd(G.redo_count, 1u)] = (uint32_t)b;
+        return;
+    }
     const int nb = A.n_bins;
     const int64_t row = b * (9 + nb);
     const u64 n = sums[10];
@@ -912,15 +991,41 @@ __global__ __launch_bounds__(FX_BLOCK) void hu_contour_hist_kernel(HuArgs A, Ban
         return fma(dyv, vy, ((double)(int)(X + i) - ccx) * vx);
     };
 
-    double top = 0.0;
-    for (int i = lane; i < qn; i += FX_WAVE) {
-        const uint32_t e = segment(i);
-        const uint32_t bits = e & 0xFFFFu, pos = e >> 16;
-        const uint32_t y = pos >> 6, X = (pos & 63u) * 16u;
-        const double dy = (double)(int)y - ccy;
-        const int lo = __ffs((int)bits) - 1, hi = 31 - __clz((int)bits);
-        top = fmax(top, fmax(fabs(sproj(X, lo, dy)), fabs(sproj(X, hi, dy))));
+    // The first KC * 64 segments (all of them for an ordinary shape) are loaded
+    // at once and kept in registers for both passes, so that the wave waits for
+    // memory once and not once per segment.
+    constexpr int KC = 16;
+    uint32_t ent[KC];
+#pragma unroll
+    for (int k = 0; k < KC; k++) {
+        const int i = lane + FX_WAVE * k;
+        ent[k] = i < qn ? segment(i) : 0u;
     }
+
+    auto ends = [&](uint32_t e, double &slo, double &shi, int &lo, int &hi, uint32_t &X, double &dy) {
+        const uint32_t bits = e & 0xFFFFu, pos = e >> 16;
+        X = (pos & 63u) * 16u;
+        dy = (double)(int)(pos >> 6) - ccy;
+        lo = __ffs((int)bits) - 1;
+        hi = 31 - __clz((int)bits);
+        slo = sproj(X, lo, dy);
+        shi = sproj(X, hi, dy);
+    };
+    auto larger = [&](uint32_t e, double best) -> double {
+        double slo, shi, dy;
+        int lo, hi;
+        uint32_t X;
+        ends(e, slo, shi, lo, hi, X, dy);
+        return fmax(best, fmax(fabs(slo), fabs(shi)));
+    };
+
+    double top = 0.0;
+#pragma unroll
+    for (int k = 0; k < KC; k++)
+        if (FX_WAVE * k < qn && ent[k])
+            top = larger(ent[k], top);
+    for (int i = lane + FX_WAVE * KC; i < qn; i += FX_WAVE)
+        top = larger(segment(i), top);
     top = fx_wave_max_f64(top);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -933,19 +1038,17 @@ __global__ __launch_bounds__(FX_BLOCK) void hu_contour_hist_kernel(HuArgs A, Ban
     }
     const double step = top / (double)nb;
     const double inv_step = (double)nb / top;
-    for (int i = lane; i < qn; i += FX_WAVE) {
-        const uint32_t e = segment(i);
-        const uint32_t bits = e & 0xFFFFu, pos = e >> 16;
-        const uint32_t y = pos >> 6, X = (pos & 63u) * 16u;
-        const double dy = (double)(int)y - ccy;
-        const int lo = __ffs((int)bits) - 1, hi = 31 - __clz((int)bits);
-        const double slo = sproj(X, lo, dy);
+    auto count = [&](uint32_t e) {
+        double slo, shi, dy;
+        int lo, hi;
+        uint32_t X;
+        ends(e, slo, shi, lo, hi, X, dy);
+        const uint32_t bits = e & 0xFFFFu;
         const int blo = fx_hist_bin(fabs(slo), step, inv_step, nb);
         if (lo == hi) {
             atomicAdd(&hist[blo], 1u);
-            continue;
+            return;
         }
-        const double shi = sproj(X, hi, dy);
         const int bhi = fx_hist_bin(fabs(shi), step, inv_step, nb);
         if (blo == bhi && ((slo < 0.0) == (shi < 0.0))) {
             atomicAdd(&hist[blo], (uint32_t)__popc(bits));
@@ -957,7 +1060,13 @@ __global__ __launch_bounds__(FX_BLOCK) void hu_contour_hist_kernel(HuArgs A, Ban
                 atomicAdd(&hist[fx_hist_bin(fabs(sproj(X, k, dy)), step, inv_step, nb)], 1u);
             }
         }
-    }
+    };
+#pragma unroll
+    for (int k = 0; k < KC; k++)
+        if (FX_WAVE * k < qn && ent[k])
+            count(ent[k]);
+    for (int i = lane + FX_WAVE * KC; i < qn; i += FX_WAVE)
+        count(segment(i));
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (lane < nb)
@@ -989,7 +1098,7 @@ __global__ void hu_groupstat_kernel(const float *hulog7, const int64_t *offsets,
 template <int MODE, bool CONTOUR>
 int launch_image_kernel(const HuArgs &A, bool aligned, size_t lds, hipStream_t s)
 {
-    dim3 grid((unsigned)A.B), block(FX_BLOCK);
+    dim3 grid((unsigned)(A.only_redo ? (A.B < 2048 ? A.B : 2048) : A.B)), block(FX_BLOCK);
     if (aligned) {
         auto k = hu_image_kernel<MODE, CONTOUR, true>;
         if (lds > 48 * 1024)
@@ -1089,7 +1198,8 @@ extern "C" int fx_hu_batch_u8(const uint8_t *d_img, int64_t B, int H, int W, int
     }
     A.rpp = FX_BLOCK / A.cpr;
     A.wrpp = FX_BLOCK / A.wpr;
-    A.redo = nullptr;
+    A.redo_count = nullptr;
+    A.redo_list = nullptr;
     A.only_redo = 0;
     const bool aligned = ((uintptr_t)d_img % 16 == 0) && (pitch_bytes % 16 == 0) && (img_stride_bytes % 16 == 0 || B == 1);
     const size_t mask_lds = LDS_HEAD_BYTES + mask_bytes;
@@ -1118,22 +1228,29 @@ extern "C" int fx_hu_batch_u8(const uint8_t *d_img, int64_t B, int H, int W, int
     // per-launch scratch: sums | queue counts | contour parameters | queues
     const size_t sums_bytes = (size_t)B * BAND_SUMS * sizeof(u64);
     const size_t count_bytes = (size_t)B * FX_WAVES_PER_BLOCK * 4;
+    const size_t redo_bytes = contour ? 16 + (((size_t)B * 4 + 15) & ~(size_t)15) : 0;
     const size_t param_bytes = contour ? (size_t)B * 4 * sizeof(double) : 0;
     const size_t queue_bytes = contour ? (size_t)B * A.qcap * 4 : 0;
-    unsigned char *base = (unsigned char *)fx_scratch(sums_bytes + count_bytes + param_bytes + queue_bytes, 1);
+    unsigned char *base = (unsigned char *)fx_scratch(sums_bytes + count_bytes + param_bytes + redo_bytes + queue_bytes, 1);
     if (!base)
         return FX_ENOMEM;
     BandScratch G;
     G.sums = (u64 *)base;
     G.qcount = (uint32_t *)(base + sums_bytes);
     G.params = (double *)(base + sums_bytes + count_bytes);
-    G.queue = (uint32_t *)(base + sums_bytes + count_bytes + param_bytes);
+    G.redo_count = (uint32_t *)(base + sums_bytes + count_bytes + param_bytes);
+    G.redo_list = G.redo_count + 4;
+    G.queue = (uint32_t *)(base + sums_bytes + count_bytes + param_bytes + redo_bytes);
+    const bool may_overflow = contour && (A.qcap >> 2) < wave_segments;
+    if (may_overflow)
+        FX_HIP_CHECK(hipMemsetAsync(G.redo_count, 0, 16, s));
 
-    const size_t band_lds = contour ? (size_t)BAND_LDS_EDGES + 4 * FX_BLOCK + (size_t)A.qcap * 4 : (size_t)LDS_HEAD_BYTES;
+    A.wave_lds = contour && A.qcap > BAND_SLAB_BYTES ? A.qcap : BAND_SLAB_BYTES;  // qcap / 4 entries of 4 bytes
+    const size_t band_lds = (size_t)BAND_LDS_WAVE + (size_t)FX_WAVES_PER_BLOCK * A.wave_lds;
     int rc;
     {
         FxProfileScope prof(s);
-        rc = launch_band(A, G, mode, contour, aligned, band_lds, s);
+        rc = launch_band(A, G, mode, contour, aligned && (W % 16 == 0), band_lds, s);
     }
     if (rc != FX_OK)
         return rc;
@@ -1145,9 +1262,10 @@ extern "C" int fx_hu_batch_u8(const uint8_t *d_img, int64_t B, int H, int W, int
     hipLaunchKernelGGL(hu_contour_hist_kernel, dim3((unsigned)((B + FX_WAVES_PER_BLOCK - 1) / FX_WAVES_PER_BLOCK)),
                        dim3(FX_BLOCK), 0, s, A, G);
     FX_HIP_CHECK(hipGetLastError());
-    if ((A.qcap >> 2) < wave_segments) {
+    if (may_overflow) {
         // images whose contour queue overflowed (very ragged masks) go through the mask kernel
-        A.redo = G.qcount;
+        A.redo_count = G.redo_count;
+        A.redo_list = G.redo_list;
         A.only_redo = 1;
         return launch_mask(A, mode, contour, aligned, mask_lds, s);
     }
