@@ -964,6 +964,7 @@ __global__ __launch_bounds__(FX_BLOCK) void hu_finalize_kernel(HuArgs A, BandScr
 __global__ __launch_bounds__(FX_BLOCK) void hu_contour_hist_kernel(HuArgs A, BandScratch G)
 {
     __shared__ uint32_t hist_all[FX_WAVES_PER_BLOCK][64];
+    __shared__ uint32_t list_all[FX_WAVES_PER_BLOCK][16 * FX_WAVE];
     const int lane = fx_lane(), wave = fx_wave();
     const int64_t b = (int64_t)blockIdx.x * FX_WAVES_PER_BLOCK + wave;
     if (b >= A.B)
@@ -1018,17 +1019,67 @@ __global__ __launch_bounds__(FX_BLOCK) void hu_contour_hist_kernel(HuArgs A, Ban
         ends(e, slo, shi, lo, hi, X, dy);
         return fmax(best, fmax(fabs(slo), fabs(shi)));
     };
+    // The same two end values in float32.  They only sort out the segments whose
+    // answer is beyond doubt: everything within `eps` of a decision boundary is
+    // decided again in float64, so the results are those of the float64 formula.
+    const float cx32 = (float)ccx, cy32 = (float)ccy, vx32 = (float)vx, vy32 = (float)vy;
+    auto ends32 = [&](uint32_t e, float &slo, float &shi) {
+        const uint32_t bits = e & 0xFFFFu, pos = e >> 16;
+        const float xb = (float)(int)((pos & 63u) * 16u) - cx32;
+        const float t = ((float)(int)(pos >> 6) - cy32) * vy32;
+        const float lo = (float)(__ffs((int)bits) - 1), hi = (float)(31 - __clz((int)bits));
+        slo = fmaf(xb + lo, vx32, t);
+        shi = fmaf(xb + hi, vx32, t);
+    };
 
+    // Segments that float32 cannot settle are collected (ballot-compacted, so
+    // that the slower code below runs with full lanes) in the wave's LDS list.
+    uint32_t *list = list_all[wave];
+    uint32_t nl = 0;  // wave-uniform
+    auto defer = [&](bool want, uint32_t e) {
+        const unsigned long long m = __ballot(want);
+        if (m) {
+            const uint32_t at = nl + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (want)
+                list[at] = e;
+            nl += (uint32_t)__popcll(m);
+        }
+    };
+    auto list_ready = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    float m32[KC];
+    float top32 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < KC; k++) {
+        m32[k] = -1.0f;
+        if (FX_WAVE * k < qn && ent[k]) {
+            float a, c;
+            ends32(ent[k], a, c);
+            m32[k] = fmaxf(fabsf(a), fabsf(c));
+            top32 = fmaxf(top32, m32[k]);
+        }
+    }
     double top = 0.0;
+    for (int i = lane + FX_WAVE * KC; i < qn; i += FX_WAVE)  // beyond the register cache: float64 directly
+        top = larger(segment(i), top);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        top32 = fmaxf(top32, __shfl_xor(top32, o, FX_WAVE));
+    // float32 error bound of a projection (coordinates below 1024, |v| <= 1): a few 1e-4; eps is generous
+    const float eps = 4e-7f * (top32 + fabsf(cx32) + fabsf(cy32) + 1024.0f);
 #pragma unroll
     for (int k = 0; k < KC; k++)
-        if (FX_WAVE * k < qn && ent[k])
-            top = larger(ent[k], top);
-    for (int i = lane + FX_WAVE * KC; i < qn; i += FX_WAVE)
-        top = larger(segment(i), top);
+        if (FX_WAVE * k < qn)
+            defer(m32[k] >= top32 - 2.0f * eps, ent[k]);  // the exact maximum is among these
+    list_ready();
+    for (uint32_t i = lane; i < nl; i += FX_WAVE)
+        top = larger(list[i], top);
     top = fx_wave_max_f64(top);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    list_ready();
+    nl = 0;
 
     float *out = A.cpca + b * (9 + nb) + 9;
     if (!(top > 0.0)) {
@@ -1038,35 +1089,52 @@ __global__ __launch_bounds__(FX_BLOCK) void hu_contour_hist_kernel(HuArgs A, Ban
     }
     const double step = top / (double)nb;
     const double inv_step = (double)nb / top;
-    auto count = [&](uint32_t e) {
-        double slo, shi, dy;
-        int lo, hi;
-        uint32_t X;
-        ends(e, slo, shi, lo, hi, X, dy);
-        const uint32_t bits = e & 0xFFFFu;
-        const int blo = fx_hist_bin(fabs(slo), step, inv_step, nb);
-        if (lo == hi) {
-            atomicAdd(&hist[blo], 1u);
-            return;
-        }
-        const int bhi = fx_hist_bin(fabs(shi), step, inv_step, nb);
-        if (blo == bhi && ((slo < 0.0) == (shi < 0.0))) {
-            atomicAdd(&hist[blo], (uint32_t)__popc(bits));
-        } else {
-            uint32_t rest = bits;
-            while (rest) {
-                const int k = __ffs((int)rest) - 1;
-                rest &= rest - 1;
-                atomicAdd(&hist[fx_hist_bin(fabs(sproj(X, k, dy)), step, inv_step, nb)], 1u);
-            }
+    // float32 bin of |s|, or -1 when |s| / step is within `margin` of an integer
+    const float inv32 = (float)inv_step;
+    const float margin = 2.0f * eps * inv32 + 1e-5f * (float)nb;
+    auto bin32 = [&](float v) -> int {
+        const float q = fabsf(v) * inv32;
+        const float f = floorf(q);
+        const float frac = q - f;
+        if (frac < margin || frac > 1.0f - margin || q >= (float)nb)
+            return -1;
+        return (int)f;
+    };
+    // one pixel at a time: float32 where it is certain, float64 otherwise
+    auto count_pixels = [&](uint32_t e) {
+        const uint32_t pos = e >> 16;
+        const uint32_t X = (pos & 63u) * 16u;
+        const float xb = (float)(int)X - cx32;
+        const float t32 = ((float)(int)(pos >> 6) - cy32) * vy32;
+        const double dy = (double)(int)(pos >> 6) - ccy;
+        uint32_t rest = e & 0xFFFFu;
+        while (rest) {
+            const int k = __ffs((int)rest) - 1;
+            rest &= rest - 1;
+            int bin = bin32(fmaf(xb + (float)k, vx32, t32));
+            if (bin < 0)
+                bin = fx_hist_bin(fabs(sproj(X, k, dy)), step, inv_step, nb);
+            atomicAdd(&hist[bin], 1u);
         }
     };
 #pragma unroll
-    for (int k = 0; k < KC; k++)
-        if (FX_WAVE * k < qn && ent[k])
-            count(ent[k]);
+    for (int k = 0; k < KC; k++) {
+        if (FX_WAVE * k < qn) {
+            float a = 0.f, c = 0.f;
+            ends32(ent[k], a, c);
+            const int ba = bin32(a), bc = bin32(c);
+            const bool same_side = (a > eps && c > eps) || (a < -eps && c < -eps);
+            const bool whole = ent[k] && ba >= 0 && ba == bc && same_side;
+            if (whole)
+                atomicAdd(&hist[ba], (uint32_t)__popc(ent[k] & 0xFFFFu));
+            defer(ent[k] && !whole, ent[k]);
+        }
+    }
+    list_ready();
+    for (uint32_t i = lane; i < nl; i += FX_WAVE)
+        count_pixels(list[i]);
     for (int i = lane + FX_WAVE * KC; i < qn; i += FX_WAVE)
-        count(segment(i));
+        count_pixels(segment(i));
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (lane < nb)
