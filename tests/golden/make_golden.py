@@ -19,6 +19,10 @@ hu_panels.npz
     of view_01 on which the production run computed Hu.  Stored bit-packed
     (masks) / as uint8 (gray panels), with the ids.
 
+preprocess_golden.npz
+    Outputs of the reference's preprocess_image / compute_otsu (no-OpenCV
+    branch) on eight of those raw view panels, with and without cropping.
+
 hu_table_rows.csv
     The rows of data/features/features_table.csv (12-view mean/std of log-Hu
     and the PCA columns) for those ids, plus reports/hu_feature_stats.csv and
@@ -120,9 +124,39 @@ def make_hu(ref: Path) -> None:
     print(f"hu_panels.npz: {len(ids)} ids; hu_table_rows.csv: {len(keep) - 1} rows")
 
 
+def make_preprocess(ref: Path) -> None:
+    """Outputs of the reference's own preprocess_image / compute_otsu (the
+    branch it takes without OpenCV: PIL + scipy.ndimage) on the raw view panels
+    of hu_panels.npz, for both crop settings.  Stored bit-packed."""
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, str(ref / "src" / "features"))
+    mod = importlib.import_module("extract_2d_hu")
+    assert not mod._HAS_CV2, "the golden masks pin the no-OpenCV branch"
+    d = np.load(HERE / "hu_panels.npz")
+    raws = d["raw_views"][:8, 0]          # view_01 of the first eight ids
+    out = {"inputs": raws}
+    for crop in (False, True):
+        pre, masks, otsu_t, otsu_m = [], [], [], []
+        for img in raws:
+            p, m = mod.preprocess_image(img.copy(), 224, 0.05, "white", crop)
+            t, om = mod.compute_otsu(img.copy())
+            pre.append(p)
+            masks.append(np.packbits(m > 127, axis=1))
+            otsu_t.append(t)
+            otsu_m.append(np.packbits(om > 127, axis=1))
+        tag = "crop" if crop else "nocrop"
+        out[f"preproc_{tag}"] = np.stack(pre)
+        out[f"mask_{tag}"] = np.stack(masks)
+    out["otsu_thresh"] = np.array(otsu_t)
+    out["otsu_mask"] = np.stack(otsu_m)
+    np.savez_compressed(HERE / "preprocess_golden.npz", **out)
+    print(f"preprocess_golden.npz: {len(raws)} images x 2 settings")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default=os.environ.get("FX_REFERENCE", "/root/reference"))
     a = ap.parse_args()
     make_pca(Path(a.reference))
     make_hu(Path(a.reference))
+    make_preprocess(Path(a.reference))

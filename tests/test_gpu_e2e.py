@@ -1,0 +1,102 @@
+"""File-level drivers on the GPU: views/ and sampled/ directories in, the
+reference's .npy + CSV outputs out, checked against the CPU oracle."""
+from argparse import Namespace
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import pkg
+
+pytestmark = pytest.mark.gpu
+
+
+def write_views(root, hu_panels, n_samples=3, views=3):
+    from PIL import Image
+    ids = []
+    for s in range(n_samples):
+        sid = f"tree_{s:02d}"
+        d = root / sid
+        d.mkdir(parents=True)
+        for v in range(views):
+            Image.fromarray(hu_panels["raw_views"][s, v]).save(d / f"view_{v + 1:02d}.png")
+        ids.append(sid)
+    return ids
+
+
+def test_hu_directory_run(gpu, tmp_path, oracle, c_oracle, hu_panels):
+    hu = pkg("extract_2d_hu")
+    views, out, rep = tmp_path / "views", tmp_path / "2d_hu", tmp_path / "reports"
+    ids = write_views(views, hu_panels)
+    (views / "tree_01" / "view_09.png").write_bytes(b"not a png")           # unreadable view: logged and skipped
+    (views / "broken").mkdir()
+    (views / "broken" / "view_01.png").write_bytes(b"junk")                 # sample without usable views
+    rc = hu.main(["--views_dir", str(views), "--out_dir", str(out), "--reports_dir", str(rep), "--preprocess_crop",
+                  "--use_silhouette", "--expected_views", "3", "--overwrite"])
+    assert rc == 0
+    df = pd.read_csv(out / "hu_features_table.csv").set_index("id")
+    assert list(df.columns) == hu.HU_COLS[1:]
+    assert set(df.index) == set(ids) | {"broken"}
+    assert df.loc["broken", "note"].startswith("failed") and np.isnan(df.loc["broken", "hu1_mean"])
+    assert df.loc["tree_00", "note"] == "ok" and df.loc["tree_01", "note"] == "ok"  # 4 files >= expected 3
+    log = (rep / "read_errors.log").read_text()
+    assert "view_09.png" in log and "broken" in log
+    for s, sid in enumerate(ids):
+        masks = [hu.preprocess_image(hu_panels["raw_views"][s, v], 224, 0.05, "white", True)[1] for v in range(3)]
+        rows = c_oracle.hu_batch(np.stack(masks))["hulog7"]
+        want = oracle.hu_groupstat(rows)[0]
+        got = df.loc[sid, hu.HU_COLS[1:15]].to_numpy(dtype=np.float64).astype(np.float32)
+        # per-view rows may differ from the oracle's by one float32 ulp (log10), the
+        # float32 mean/std of 3 rows then by a few ulps
+        np.testing.assert_allclose(got[:7], want[:7], rtol=1e-6)
+        np.testing.assert_allclose(got[7:], want[7:], rtol=1e-4, atol=1e-6)
+        saved = np.load(out / f"{sid}_hu.npy")
+        assert saved.dtype == np.float32 and saved.shape == (14,)
+        np.testing.assert_array_equal(saved, got)
+    assert (rep / "hu_feature_stats.csv").exists() and (out / "extract_2d_hu_config.yaml").exists()
+
+
+def test_hu_worker_dict_contract(gpu, tmp_path, hu_panels):
+    hu = pkg("extract_2d_hu")
+    views = tmp_path / "views"
+    write_views(views, hu_panels, n_samples=1, views=2)
+    cfg = {"out_dir": str(tmp_path / "o"), "resolution": 224, "use_silhouette": False, "preprocess_crop": False,
+           "crop_margin": 0.05, "bg_color": "white", "expected_views": 12, "overwrite": True,
+           "reports_dir": str(tmp_path / "r")}
+    res = hu.process_sample_worker(("tree_00", str(views / "tree_00"), cfg))
+    assert set(res) == {"success", "id", "vec", "note"}
+    assert res["success"] and res["id"] == "tree_00" and len(res["vec"]) == 14 and res["note"] == "partial_views"
+    miss = hu.process_sample_worker(("nope", str(views / "nope"), cfg))
+    assert not miss["success"] and miss["vec"] is None and miss["note"].startswith("failed: No view images")
+
+
+def test_pca_directory_run_and_merge(gpu, tmp_path, oracle):
+    pca, mf, synth = pkg("extract_3d_pca_features"), pkg("merge_features"), pkg("synth")
+    sampled, out, rep = tmp_path / "processed" / "sampled", tmp_path / "desc", tmp_path / "reports"
+    sampled.mkdir(parents=True)
+    clouds = synth.points_host(5, 1024, seed=8)
+    for k in range(5):
+        np.save(sampled / f"cloud_{k}.npy", clouds[k])
+    np.save(sampled / "cloud_small.npy", np.zeros((2, 3), np.float32))        # dropped from the table
+    np.save(sampled / "cloud_big.npy", synth.points_host(1, 5000, seed=9)[0])  # other size: ragged batch
+    pd.DataFrame({"id": ["cloud_0"], "raw_path": ["/raw/cloud_0.pts"]}).to_csv(tmp_path / "processed" / "manifest.csv", index=False)
+    rc = pca.main(["--sampled_dir", str(sampled), "--out_dir", str(out), "--reports_dir", str(rep), "--n_bins", "8"])
+    assert rc == 0
+    df = pd.read_csv(out / "descriptors_table_pca.csv").set_index("id")
+    assert list(df.columns) == pca.column_names(8)[1:]
+    assert "cloud_small" not in df.index and len(df) == 6
+    assert df.loc["cloud_0", "raw_path"] == "/raw/cloud_0.pts" and df.loc["cloud_big", "n_points"] == 5000
+    for k in range(5):
+        want = oracle.compute_pca_features(clouds[k].astype(np.float64))
+        got = df.loc[f"cloud_{k}", pca.column_names(8)[3:]].to_numpy(dtype=np.float64)
+        np.testing.assert_allclose(got[:9], want[:9], rtol=1e-6)
+        assert np.abs(got[9:] - want[9:]).max() * 1024 <= 2.5
+        np.testing.assert_array_equal(np.load(out / f"pca_cloud_{k}.npy"), got.astype(np.float32))
+    assert "cloud_small" in (rep / "read_errors.log").read_text()
+    # merge with a Hu table: the reference's joined layout
+    hu_cols = pkg("extract_2d_hu").HU_COLS
+    pd.DataFrame([[f"cloud_{k}"] + [float(k)] * 14 + ["ok"] for k in range(3)], columns=hu_cols).to_csv(tmp_path / "hu.csv", index=False)
+    mf.main(Namespace(hu_csv=str(tmp_path / "hu.csv"), pca_csv=str(out / "descriptors_table_pca.csv"), out=str(tmp_path / "features.csv")))
+    m = pd.read_csv(tmp_path / "features.csv").set_index("id")
+    assert len(m) == 6 and m.loc["cloud_4", "hu1_mean"] == 0 and m.loc["cloud_2", "hu1_mean"] == 2.0
+    assert m.loc["cloud_1", "lambda1"] == pytest.approx(df.loc["cloud_1", "lambda1"])
