@@ -44,6 +44,9 @@ struct HuArgs {
     // consecutive rows; qcap entries fit in the contour queue
     int bpw, nbands, hb, qcap;
     int wave_lds;  // bytes of LDS per wave: its queue part, at least the 4 KiB reduction slab
+    // tiled mode (images larger than one block handles): the band kernel runs on
+    // TILE_W x TILE_H tiles, tiles_x * tiles_y blocks per image, sums stay tile-local
+    int tiles_x, tiles_y;
     // images whose band-kernel contour queue overflowed; the mask kernel redoes them
     const uint32_t *redo_count;
     const uint32_t *redo_list;
@@ -582,6 +585,7 @@ constexpr int BAND_LDS_EDGES = BAND_LDS_COUNTERS + 16;     // top/bottom row mas
 // has been consumed by then) the 4 KiB slab of the wave-level reduction
 constexpr int BAND_LDS_WAVE = BAND_LDS_EDGES + 4 * FX_BLOCK;
 constexpr int BAND_SLAB_BYTES = 4096;
+constexpr int TILE_W = 1024, TILE_H = 256;                 // tiled mode: one block per tile, 64 rows per wave
 constexpr int BAND_SUMS = 16;                              // u64 per image: 10 raw moments + 6 contour sums
 
 struct BandScratch {
@@ -628,15 +632,25 @@ __global__ __launch_bounds__(FX_BLOCK, FX_BAND_WAVES) void hu_band_kernel(HuArgs
 
     const int t = threadIdx.x;
     const int lane = fx_lane(), wave = fx_wave();
-    const int64_t b = blockIdx.x;
+    const int64_t b = blockIdx.x;  // image, or (image, tile) in tiled mode
     const uint8_t *img = A.img + b * A.stride;
-    const int H = A.H, W = A.W, cpr = A.cpr, hb = A.hb;
+    int H = A.H, W = A.W;
+    if (A.tiles_x > 0) {
+        const int tiles = A.tiles_x * A.tiles_y;
+        const int64_t image = b / tiles;
+        const int tile = (int)(b - image * tiles);
+        const int tyi = tile / A.tiles_x, txi = tile - tyi * A.tiles_x;
+        img = A.img + image * A.stride + (int64_t)tyi * TILE_H * A.pitch + (int64_t)txi * TILE_W;
+        H = min(TILE_H, A.H - tyi * TILE_H);
+        W = min(TILE_W, A.W - txi * TILE_W);
+    }
+    const int cpr = A.cpr, hb = A.hb;
 
     const int bl = lane / cpr, tx = lane - bl * cpr;
-    const bool active = bl < A.bpw;
+    const int x0 = tx * 16;
+    const bool active = bl < A.bpw && x0 < W;
     const int band = wave * A.bpw + bl;
     const int ya = band * hb;
-    const int x0 = tx * 16;
     const uint32_t kthr = (uint32_t)(255 - (A.thresh < 0 ? 127 : A.thresh)) * 0x00010001u;
 
     // ALIGNED: every chunk is a whole, 16-byte aligned vector.  The load is then
@@ -956,6 +970,50 @@ __global__ __launch_bounds__(FX_BLOCK) void hu_finalize_kernel(HuArgs A, BandScr
     p[3] = v1[1];
 }
 
+// Tiled mode, one lane per image: shift every tile's local sums to image
+// coordinates and add them up in exact 128-bit integers, round each raw moment
+// once to double (for images up to 512 x 512 this is the value OpenCV's
+// double accumulation holds exactly; beyond, it is the value that accumulation
+// approximates), then finalise as usual.
+__global__ __launch_bounds__(FX_BLOCK) void hu_tile_combine_kernel(HuArgs A, BandScratch G, int gray)
+{
+    typedef unsigned __int128 u128;
+    const int64_t b = (int64_t)blockIdx.x * FX_BLOCK + threadIdx.x;
+    if (b >= A.B)
+        return;
+    const int tiles = A.tiles_x * A.tiles_y;
+    u128 M[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++)
+        M[k] = 0;
+    for (int tile = 0; tile < tiles; tile++) {
+        const u64 *t = G.sums + (b * tiles + tile) * BAND_SUMS;
+        const int tyi = tile / A.tiles_x, txi = tile - tyi * A.tiles_x;
+        const u128 X = (u128)(txi * TILE_W), Y = (u128)(tyi * TILE_H);
+        const u128 t00 = t[0], t10 = t[1], t01 = t[2], t20 = t[3], t11 = t[4], t02 = t[5];
+        const u128 t30 = t[6], t21 = t[7], t12 = t[8], t03 = t[9];
+        M[0] += t00;
+        M[1] += t10 + X * t00;
+        M[2] += t01 + Y * t00;
+        M[3] += t20 + 2 * X * t10 + X * X * t00;
+        M[4] += t11 + X * t01 + Y * t10 + X * Y * t00;
+        M[5] += t02 + 2 * Y * t01 + Y * Y * t00;
+        M[6] += t30 + 3 * X * t20 + 3 * X * X * t10 + X * X * X * t00;
+        M[7] += t21 + 2 * X * t11 + X * X * t01 + Y * t20 + 2 * X * Y * t10 + X * X * Y * t00;
+        M[8] += t12 + 2 * Y * t11 + Y * Y * t10 + X * t02 + 2 * X * Y * t01 + X * Y * Y * t00;
+        M[9] += t03 + 3 * Y * t02 + 3 * Y * Y * t01 + Y * Y * Y * t00;
+    }
+    const u128 scale = gray ? 1 : (u128)A.on_value;
+    double raw[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+        const u128 v = M[k] * scale;
+        raw[k] = fx_u128_to_double((u64)(v >> 64), (u64)v);
+    }
+    finalize_moments(raw, A.moments24 ? A.moments24 + b * 24 : nullptr, A.hu7 ? A.hu7 + b * 7 : nullptr,
+                     A.hulog7 ? A.hulog7 + b * 7 : nullptr);
+}
+
 // One wave per image: largest |projection on PC1| over the contour pixels and
 // the histogram of it, from the queued segments.  Along a segment the signed
 // projection is monotone in x, so its largest magnitude is at an end, and a
@@ -1185,7 +1243,8 @@ int launch_image_kernel(const HuArgs &A, bool aligned, size_t lds, hipStream_t s
 template <int MODE, bool CONTOUR>
 int launch_band_kernel(const HuArgs &A, const BandScratch &G, bool aligned, size_t lds, hipStream_t s)
 {
-    dim3 grid((unsigned)A.B), block(FX_BLOCK);
+    const int64_t blocks = A.tiles_x > 0 ? A.B * A.tiles_x * A.tiles_y : A.B;
+    dim3 grid((unsigned)blocks), block(FX_BLOCK);
     if (aligned)
         hipLaunchKernelGGL((hu_band_kernel<MODE, CONTOUR, true>), grid, block, lds, s, A, G);
     else
@@ -1259,31 +1318,73 @@ extern "C" int fx_hu_batch_u8(const uint8_t *d_img, int64_t B, int H, int W, int
 
     const bool contour = d_cpca != nullptr;
     const size_t mask_bytes = contour ? (size_t)(H + 2) * A.wpr * 4 : 0;
-    const bool single_block = W <= 2048 && H <= 2048 && mask_bytes <= 128 * 1024;
-    if (!single_block) {
-        fx_set_error("fx_hu_batch_u8: images larger than 2048 x 2048 (or contour masks over 128 KiB) are not supported yet");
-        return FX_EINVAL;
-    }
-    A.rpp = FX_BLOCK / A.cpr;
-    A.wrpp = FX_BLOCK / A.wpr;
+    A.rpp = A.cpr <= FX_BLOCK ? FX_BLOCK / A.cpr : 0;
+    A.wrpp = A.wpr <= FX_BLOCK ? FX_BLOCK / A.wpr : 0;
     A.redo_count = nullptr;
     A.redo_list = nullptr;
     A.only_redo = 0;
+    A.tiles_x = A.tiles_y = 0;
     const bool aligned = ((uintptr_t)d_img % 16 == 0) && (pitch_bytes % 16 == 0) && (img_stride_bytes % 16 == 0 || B == 1);
     const size_t mask_lds = LDS_HEAD_BYTES + mask_bytes;
     const int mode = thresh < 0 ? MODE_GRAY : (thresh == 127 ? MODE_BIT7 : MODE_THRESH);
 
-    // Band kernel: a row must fit in one wave and a queue position (row, chunk)
-    // in 10 + 6 bits.
+    // Which organisation:
+    //   band   images up to 1024 x 1024: a row fits in one wave and a queue
+    //          position (row, chunk) in 10 + 6 bits;
+    //   mask   contour descriptor of images up to 2048 x 2048 whose bit mask fits in LDS;
+    //   tiled  anything larger, Hu only: band kernel per 1024 x 256 tile + 128-bit combine.
     bool band = A.cpr <= FX_WAVE && H <= 1024;
     const char *force = getenv("FX_HU_KERNEL");  // "mask": development switch
-    if (force && strcmp(force, "mask") == 0)
+    const bool mask_ok = W <= 2048 && H <= 2048 && mask_bytes <= 128 * 1024;
+    if (force && strcmp(force, "mask") == 0 && mask_ok)
         band = false;
 
-    // launch timing (when switched on) brackets the streaming kernel only
-    if (!band) {
+    if (!band && contour) {
+        if (!mask_ok) {
+            fx_set_error("fx_hu_batch_u8: the contour descriptor supports images up to 2048 x 2048 with at most "
+                         "128 KiB of bit mask (got %d x %d); Hu moments alone have no such limit", H, W);
+            return FX_EINVAL;
+        }
+        FxProfileScope prof(s);  // launch timing (when switched on) brackets the streaming kernel only
+        return launch_mask(A, mode, contour, aligned, mask_lds, s);
+    }
+    if (!band && force && strcmp(force, "mask") == 0 && mask_ok) {
         FxProfileScope prof(s);
         return launch_mask(A, mode, contour, aligned, mask_lds, s);
+    }
+
+    if (!band) {
+        // tiled: the band kernel sees 1024 x 256 tiles (one 64-row band per wave)
+        A.tiles_x = (W + TILE_W - 1) / TILE_W;
+        A.tiles_y = (H + TILE_H - 1) / TILE_H;
+        const int64_t blocks = B * A.tiles_x * A.tiles_y;
+        FX_REQUIRE(blocks <= 0x7fffffffLL, "fx_hu_batch_u8: too many tiles for one launch");
+        A.cpr = FX_WAVE;
+        A.bpw = 1;
+        A.nbands = FX_WAVES_PER_BLOCK;
+        A.hb = TILE_H / FX_WAVES_PER_BLOCK;
+        A.qcap = 0;
+        A.wave_lds = BAND_SLAB_BYTES;
+        BandScratch G;
+        G.sums = (u64 *)fx_scratch((size_t)blocks * BAND_SUMS * sizeof(u64), 1);
+        if (!G.sums)
+            return FX_ENOMEM;
+        G.qcount = nullptr;
+        G.queue = nullptr;
+        G.params = nullptr;
+        G.redo_count = nullptr;
+        G.redo_list = nullptr;
+        int rc;
+        {
+            FxProfileScope prof(s);
+            rc = launch_band(A, G, mode, false, aligned && (W % 16 == 0), (size_t)BAND_LDS_WAVE + (size_t)FX_WAVES_PER_BLOCK * A.wave_lds, s);
+        }
+        if (rc != FX_OK)
+            return rc;
+        hipLaunchKernelGGL(hu_tile_combine_kernel, dim3((unsigned)((B + FX_BLOCK - 1) / FX_BLOCK)), dim3(FX_BLOCK), 0, s, A, G,
+                           mode == MODE_GRAY ? 1 : 0);
+        FX_HIP_CHECK(hipGetLastError());
+        return FX_OK;
     }
 
     A.bpw = FX_WAVE / A.cpr;

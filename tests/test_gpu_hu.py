@@ -127,6 +127,36 @@ def test_contour_descriptor(gpu, oracle, size, nb):
     assert ties <= 2
 
 
+@pytest.mark.parametrize("size,B", [((2048, 2048), 2), ((1100, 1030), 3), ((3000, 4100), 2), ((8192, 8192), 1), ((1025, 16), 2)])
+def test_large_images_tiled_path(gpu, c_oracle, size, B):
+    """Images beyond 1024 x 1024 are cut into tiles whose integer sums are
+    combined in 128-bit arithmetic: the raw moments are the exact integers,
+    rounded once to double (OpenCV's own double accumulation deviates from them
+    by rounding only, see test_oracle.py)."""
+    H, W = size
+    eng = pkg("engine")
+    dev = eng.synth_shapes(B, H, W, seed=13, device=gpu)
+    imgs = dev.cpu().numpy()
+    res = eng.hu_batch(dev, thresh=127, moments=True, hu=True)
+    got = {k: v.cpu().numpy() for k, v in res.items()}
+    ref = c_oracle.hu_batch(imgs, thresh=127, exact=True)
+    check_against_oracle(got, ref)
+    near = c_oracle.hu_batch(imgs, thresh=127, exact=False)  # OpenCV's tile order
+    np.testing.assert_allclose(got["moments24"][:, :10], near["moments24"][:, :10], rtol=1e-12)
+    np.testing.assert_allclose(got["hulog7"][:, :4], near["hulog7"][:, :4], rtol=1e-5)
+    # gray weights through the same path
+    g = eng.hu_batch(dev // 3 + 7, thresh=-1, moments=True, hu=True)
+    check_against_oracle({k: v.cpu().numpy() for k, v in g.items()}, c_oracle.hu_batch(imgs // 3 + 7, exact=True))
+
+
+def test_contour_on_oversized_image_is_rejected(gpu):
+    import torch
+    eng, lib = pkg("engine"), pkg("_lib")
+    big = torch.zeros((1, 4096, 4096), dtype=torch.uint8, device=gpu)
+    with pytest.raises(lib.FxError, match="contour descriptor supports images up to"):
+        eng.hu_batch(big, thresh=127, contour_bins=8)
+
+
 def test_ragged_masks_overflow_path(gpu, oracle, c_oracle):
     """Noise images have a contour segment in almost every 16-pixel chunk, far
     beyond the on-chip segment queue: such images are redone by the mask kernel."""
