@@ -218,82 +218,149 @@ __global__ __launch_bounds__(FX_WAVE *WPB) void pca_sets_wave_kernel(PcaArgs A)
 }
 
 // ---------------------------------------------------------------- large sets
-constexpr int CLOUD_BLOCK = 512;
-constexpr int CLOUD_WAVES = CLOUD_BLOCK / FX_WAVE;
+// Clouds that do not fit a wave's LDS slab are cut into chunks of CLOUD_CHUNK
+// points; every pass over the data is one launch with one block per chunk, so
+// a 4M-point cloud spreads over 256 blocks instead of serialising on one, and
+// a batch of unequal clouds is balanced at chunk granularity.  Partial results
+// go to a per-chunk record; the next launch's blocks combine the records of
+// their own cloud (in a fixed tree order: results do not depend on scheduling).
+constexpr int CLOUD_CHUNK = 16384;
+constexpr int CLOUD_THREADS = 256;
+constexpr int CLOUD_WAVES = CLOUD_THREADS / FX_WAVE;
+// per-chunk record, doubles: 0-2 coordinate sums, 3 max r^2, 4-9 centred second moments, 10 max |projection|
+constexpr int PART = 12;
+// per-cloud record, doubles: 0-2 mean, 3 rmax (0 = no scaling), 4-6 first principal axis
+constexpr int STATE = 8;
 
-__device__ __forceinline__ double cloud_sum(double v, double *red)
+struct CloudWork {
+    const int32_t *cloud_ids;    // [n_clouds] set index of every large cloud
+    const int32_t *cloud_first;  // [n_clouds + 1] first chunk of every cloud
+    const int32_t *chunk_cloud;  // [n_chunks] position in cloud_ids of the chunk's cloud
+    double *part;                // [n_chunks][PART]
+    uint32_t *hpart;             // [n_chunks][HIST_MAX]
+    double *state;               // [n_clouds][STATE]
+};
+
+struct ChunkView {
+    const float *g;   // first point of the cloud
+    int64_t n;        // points in the cloud
+    int64_t i0, i1;   // this chunk's point range
+    int64_t set;
+    int cloud, first, nch;
+};
+
+__device__ __forceinline__ ChunkView chunk_view(const PcaArgs &A, const CloudWork &Wk, int c)
 {
-    v = fx_wave_sum_f64(v);
-    if (fx_lane() == 0)
-        red[fx_wave()] = v;
-    __syncthreads();
-    double s = 0.0;
-#pragma unroll
-    for (int w = 0; w < CLOUD_WAVES; w++)
-        s += red[w];
-    __syncthreads();
-    return s;
+    ChunkView v;
+    v.cloud = Wk.chunk_cloud[c];
+    v.set = Wk.cloud_ids[v.cloud];
+    v.first = Wk.cloud_first[v.cloud];
+    v.nch = Wk.cloud_first[v.cloud + 1] - v.first;
+    if (A.offsets) {
+        const int64_t a = A.offsets[v.set];
+        v.n = A.offsets[v.set + 1] - a;
+        v.g = A.pts + a * A.dims;
+    } else {
+        v.n = A.N;
+        v.g = A.pts + v.set * A.N * A.dims;
+    }
+    v.i0 = (int64_t)(c - v.first) * CLOUD_CHUNK;
+    v.i1 = v.i0 + CLOUD_CHUNK < v.n ? v.i0 + CLOUD_CHUNK : v.n;
+    return v;
 }
 
-__device__ __forceinline__ double cloud_max(double v, double *red)
+template <bool MAX>
+__device__ __forceinline__ double cloud_block_reduce(double v, double *red)
 {
-    v = fx_wave_max_f64(v);
+    v = MAX ? fx_wave_max_f64(v) : fx_wave_sum_f64(v);
     if (fx_lane() == 0)
         red[fx_wave()] = v;
     __syncthreads();
     double s = red[0];
 #pragma unroll
     for (int w = 1; w < CLOUD_WAVES; w++)
-        s = fmax(s, red[w]);
+        s = MAX ? fmax(s, red[w]) : s + red[w];
     __syncthreads();
     return s;
 }
 
-__global__ __launch_bounds__(CLOUD_BLOCK) void pca_cloud_block_kernel(PcaArgs A)
+// Combines field k of the records of chunks first .. first+nch-1; every thread gets the result.
+template <bool MAX>
+__device__ __forceinline__ double cloud_combine(const double *part, int first, int nch, int k, double *red)
+{
+    double v = 0.0;
+    for (int i = threadIdx.x; i < nch; i += CLOUD_THREADS) {
+        const double p = part[(int64_t)(first + i) * PART + k];
+        v = MAX ? fmax(v, p) : v + p;
+    }
+    return cloud_block_reduce<MAX>(v, red);
+}
+
+struct CloudPoint {
+    double x, y, z;
+};
+__device__ __forceinline__ CloudPoint cloud_point(const float *g, int64_t i, int dims)
+{
+    CloudPoint p;
+    p.x = (double)g[i * dims];
+    p.y = (double)g[i * dims + 1];
+    p.z = dims == 3 ? (double)g[i * dims + 2] : 0.0;
+    return p;
+}
+
+__global__ __launch_bounds__(CLOUD_THREADS) void cloud_sum_kernel(PcaArgs A, CloudWork Wk)
 {
     __shared__ double red[CLOUD_WAVES];
-    __shared__ uint32_t hist[HIST_MAX];
-    const int t = threadIdx.x;
-    const SetView sv = resolve_set(A, blockIdx.x);
-    const int64_t set = sv.set, n = sv.n;
-    const int dims = A.dims;
-    const float *g = sv.base;
-    if (n < 3) {
-        write_nan_row(A, set, t, CLOUD_BLOCK);
-        return;
-    }
-    if (t < HIST_MAX)
-        hist[t] = 0;
-
-    auto px = [&](int64_t i) -> double { return (double)g[i * dims]; };
-    auto py = [&](int64_t i) -> double { return (double)g[i * dims + 1]; };
-    auto pz = [&](int64_t i) -> double { return dims == 3 ? (double)g[i * dims + 2] : 0.0; };
-
+    const ChunkView v = chunk_view(A, Wk, blockIdx.x);
     double sx = 0.0, sy = 0.0, sz = 0.0;
-    for (int64_t i = t; i < n; i += CLOUD_BLOCK) {
-        sx += px(i);
-        sy += py(i);
-        sz += pz(i);
+    for (int64_t i = v.i0 + threadIdx.x; i < v.i1; i += CLOUD_THREADS) {
+        const CloudPoint p = cloud_point(v.g, i, A.dims);
+        sx += p.x;
+        sy += p.y;
+        sz += p.z;
     }
-    const double dn = (double)n;
-    const double mx = cloud_sum(sx, red) / dn;
-    const double my = cloud_sum(sy, red) / dn;
-    const double mz = cloud_sum(sz, red) / dn;
+    sx = cloud_block_reduce<false>(sx, red);
+    sy = cloud_block_reduce<false>(sy, red);
+    sz = cloud_block_reduce<false>(sz, red);
+    if (threadIdx.x == 0) {
+        double *out = Wk.part + (int64_t)blockIdx.x * PART;
+        out[0] = sx;
+        out[1] = sy;
+        out[2] = sz;
+    }
+}
 
-    double rmax = 0.0;
-    if (A.normalize) {
+// STAGE 0: max r^2 of the centred points (normalize only); STAGE 1: centred second moments.
+template <int STAGE>
+__global__ __launch_bounds__(CLOUD_THREADS) void cloud_moment_kernel(PcaArgs A, CloudWork Wk)
+{
+    __shared__ double red[CLOUD_WAVES];
+    const ChunkView v = chunk_view(A, Wk, blockIdx.x);
+    const double dn = (double)v.n;
+    const double mx = cloud_combine<false>(Wk.part, v.first, v.nch, 0, red) / dn;
+    const double my = cloud_combine<false>(Wk.part, v.first, v.nch, 1, red) / dn;
+    const double mz = cloud_combine<false>(Wk.part, v.first, v.nch, 2, red) / dn;
+    double *out = Wk.part + (int64_t)blockIdx.x * PART;
+    if (STAGE == 0) {
         double r2 = 0.0;
-        for (int64_t i = t; i < n; i += CLOUD_BLOCK) {
-            const double dx = px(i) - mx, dy = py(i) - my, dz = pz(i) - mz;
+        for (int64_t i = v.i0 + threadIdx.x; i < v.i1; i += CLOUD_THREADS) {
+            const CloudPoint p = cloud_point(v.g, i, A.dims);
+            const double dx = p.x - mx, dy = p.y - my, dz = p.z - mz;
             r2 = fmax(r2, dx * dx + dy * dy + dz * dz);
         }
-        rmax = sqrt(cloud_max(r2, red));
+        r2 = cloud_block_reduce<true>(r2, red);
+        if (threadIdx.x == 0)
+            out[3] = r2;
+        return;
     }
+    double rmax = 0.0;
+    if (A.normalize)
+        rmax = sqrt(cloud_combine<true>(Wk.part, v.first, v.nch, 3, red));
     const bool scale = A.normalize && rmax > 0.0;
-
     double S[6] = {0, 0, 0, 0, 0, 0};
-    for (int64_t i = t; i < n; i += CLOUD_BLOCK) {
-        double dx = px(i) - mx, dy = py(i) - my, dz = pz(i) - mz;
+    for (int64_t i = v.i0 + threadIdx.x; i < v.i1; i += CLOUD_THREADS) {
+        const CloudPoint p = cloud_point(v.g, i, A.dims);
+        double dx = p.x - mx, dy = p.y - my, dz = p.z - mz;
         if (scale) {
             dx /= rmax;
             dy /= rmax;
@@ -307,49 +374,128 @@ __global__ __launch_bounds__(CLOUD_BLOCK) void pca_cloud_block_kernel(PcaArgs A)
         S[5] = fma(dz, dz, S[5]);
     }
 #pragma unroll
-    for (int k = 0; k < 6; k++)
-        S[k] = cloud_sum(S[k], red);
-
-    double head[9], lam[3], v1[3];
-    cov_to_head(S, n, head, lam, v1);
-
-    auto proj = [&](int64_t i) -> double {
-        double dx = px(i) - mx, dy = py(i) - my, dz = pz(i) - mz;
-        if (scale) {
-            dx /= rmax;
-            dy /= rmax;
-            dz /= rmax;
-        }
-        return fabs(fma(dz, v1[2], fma(dy, v1[1], dx * v1[0])));
-    };
-    double top = 0.0;
-    for (int64_t i = t; i < n; i += CLOUD_BLOCK)
-        top = fmax(top, proj(i));
-    top = cloud_max(top, red);
-
-    const int nb = A.n_bins;
-    const int width = 9 + nb;
-    if (top > 0.0) {
-        const double step = top / (double)nb;
-        const double inv_step = (double)nb / top;
-        for (int64_t i = t; i < n; i += CLOUD_BLOCK)
-            atomicAdd(&hist[fx_hist_bin(proj(i), step, inv_step, nb)], 1u);
-        __syncthreads();
-        if (t < nb)
-            A.out[set * width + 9 + t] = (float)((double)hist[t] / dn);
-    } else if (t < nb) {
-        A.out[set * width + 9 + t] = t == 0 ? 1.0f : 0.0f;
+    for (int k = 0; k < 6; k++) {
+        const double tot = cloud_block_reduce<false>(S[k], red);
+        if (threadIdx.x == 0)
+            out[4 + k] = tot;
     }
-    if (t == 0) {
-        for (int k = 0; k < 9; k++)
-            A.out[set * width + k] = (float)head[k];
-        if (A.eig) {
-            for (int k = 0; k < 3; k++) {
-                A.eig[set * 6 + k] = lam[k];
-                A.eig[set * 6 + 3 + k] = v1[k];
+    if (threadIdx.x == 0 && blockIdx.x == (unsigned)v.first) {
+        double *st = Wk.state + (int64_t)v.cloud * STATE;
+        st[0] = mx;
+        st[1] = my;
+        st[2] = mz;
+        st[3] = scale ? rmax : 0.0;
+    }
+}
+
+__device__ __forceinline__ double cloud_projection(const CloudPoint &p, const double *st)
+{
+    double dx = p.x - st[0], dy = p.y - st[1], dz = p.z - st[2];
+    if (st[3] > 0.0) {
+        dx /= st[3];
+        dy /= st[3];
+        dz /= st[3];
+    }
+    return fabs(fma(dz, st[6], fma(dy, st[5], dx * st[4])));
+}
+
+// Covariance -> eigen-solve (every block of the cloud repeats it: a few hundred
+// instructions) -> largest |projection| of the chunk.  The cloud's first block
+// also writes the nine scalars and the axis.
+__global__ __launch_bounds__(CLOUD_THREADS) void cloud_proj_kernel(PcaArgs A, CloudWork Wk)
+{
+    __shared__ double red[CLOUD_WAVES];
+    const ChunkView v = chunk_view(A, Wk, blockIdx.x);
+    double S[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+        S[k] = cloud_combine<false>(Wk.part, v.first, v.nch, 4 + k, red);
+    double head[9], lam[3], v1[3];
+    cov_to_head(S, v.n, head, lam, v1);
+    double st[STATE];
+    const double *gs = Wk.state + (int64_t)v.cloud * STATE;
+    st[0] = gs[0];
+    st[1] = gs[1];
+    st[2] = gs[2];
+    st[3] = gs[3];
+    st[4] = v1[0];
+    st[5] = v1[1];
+    st[6] = v1[2];
+    double top = 0.0;
+    for (int64_t i = v.i0 + threadIdx.x; i < v.i1; i += CLOUD_THREADS)
+        top = fmax(top, cloud_projection(cloud_point(v.g, i, A.dims), st));
+    top = cloud_block_reduce<true>(top, red);
+    if (threadIdx.x == 0) {
+        Wk.part[(int64_t)blockIdx.x * PART + 10] = top;
+        if (blockIdx.x == (unsigned)v.first) {
+            const int width = 9 + A.n_bins;
+            for (int k = 0; k < 9; k++)
+                A.out[v.set * width + k] = (float)head[k];
+            if (A.eig) {
+                for (int k = 0; k < 3; k++) {
+                    A.eig[v.set * 6 + k] = lam[k];
+                    A.eig[v.set * 6 + 3 + k] = v1[k];
+                }
             }
         }
     }
+    // the axis goes to the cloud record for the histogram pass; every block of
+    // the cloud computed the same values, the first one stores them
+    if (threadIdx.x == 0 && blockIdx.x == (unsigned)v.first) {
+        double *wst = Wk.state + (int64_t)v.cloud * STATE;
+        wst[4] = v1[0];
+        wst[5] = v1[1];
+        wst[6] = v1[2];
+    }
+}
+
+__global__ __launch_bounds__(CLOUD_THREADS) void cloud_hist_kernel(PcaArgs A, CloudWork Wk)
+{
+    __shared__ double red[CLOUD_WAVES];
+    __shared__ uint32_t hist[HIST_MAX];
+    const ChunkView v = chunk_view(A, Wk, blockIdx.x);
+    if (threadIdx.x < HIST_MAX)
+        hist[threadIdx.x] = 0;
+    const double top = cloud_combine<true>(Wk.part, v.first, v.nch, 10, red);  // its barriers cover the zeroing
+    double st[STATE];
+    const double *gs = Wk.state + (int64_t)v.cloud * STATE;
+#pragma unroll
+    for (int k = 0; k < 7; k++)
+        st[k] = gs[k];
+    const int nb = A.n_bins;
+    if (top > 0.0) {
+        const double step = top / (double)nb;
+        const double inv_step = (double)nb / top;
+        for (int64_t i = v.i0 + threadIdx.x; i < v.i1; i += CLOUD_THREADS)
+            atomicAdd(&hist[fx_hist_bin(cloud_projection(cloud_point(v.g, i, A.dims), st), step, inv_step, nb)], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < HIST_MAX)
+        Wk.hpart[(int64_t)blockIdx.x * HIST_MAX + threadIdx.x] = hist[threadIdx.x];
+}
+
+// One wave per cloud: add the chunk histograms, normalise, write.
+__global__ __launch_bounds__(FX_WAVE) void cloud_finish_kernel(PcaArgs A, CloudWork Wk)
+{
+    const int cloud = blockIdx.x, lane = threadIdx.x;
+    const int first = Wk.cloud_first[cloud], nch = Wk.cloud_first[cloud + 1] - first;
+    const int64_t set = Wk.cloud_ids[cloud];
+    const int64_t n = A.offsets ? A.offsets[set + 1] - A.offsets[set] : A.N;
+    double top = 0.0;
+    for (int i = 0; i < nch; i++)
+        top = fmax(top, Wk.part[(int64_t)(first + i) * PART + 10]);
+    const int nb = A.n_bins;
+    if (lane >= nb)
+        return;
+    float *out = A.out + set * (9 + nb) + 9;
+    if (!(top > 0.0)) {
+        out[lane] = lane == 0 ? 1.0f : 0.0f;
+        return;
+    }
+    u64 cnt = 0;
+    for (int i = 0; i < nch; i++)
+        cnt += Wk.hpart[(int64_t)(first + i) * HIST_MAX + lane];
+    out[lane] = (float)((double)cnt / (double)n);
 }
 
 constexpr int64_t WAVE_SET_MAX_POINTS = 2048;  // sets up to this size take the LDS path
@@ -375,6 +521,68 @@ int launch_small_sets(const PcaArgs &A, int64_t max_points, hipStream_t s)
     if (max_points <= 1024)
         return launch_wave_kernel<4>(A, max_points, s);
     return launch_wave_kernel<2>(A, max_points, s);
+}
+
+// Builds the chunk lists for the given large clouds (set index + point count,
+// host arrays) and runs the passes.
+int launch_large_clouds(const PcaArgs &A, const int32_t *h_sets, const int64_t *h_sizes, int64_t n_clouds, hipStream_t s)
+{
+    int64_t n_chunks = 0;
+    for (int64_t k = 0; k < n_clouds; k++)
+        n_chunks += (h_sizes[k] + CLOUD_CHUNK - 1) / CLOUD_CHUNK;
+    FX_REQUIRE(n_chunks <= 0x7fffffffLL && n_clouds <= 0x7fffffffLL, "fx_pca_batch_f32: too many chunks for one launch");
+    const size_t ints = (size_t)n_clouds + (size_t)(n_clouds + 1) + (size_t)n_chunks;
+    int32_t *h = (int32_t *)malloc(ints * sizeof(int32_t));
+    if (!h) {
+        fx_set_error("fx_pca_batch_f32: host allocation failed");
+        return FX_ENOMEM;
+    }
+    int32_t *h_ids = h, *h_first = h + n_clouds, *h_cc = h_first + n_clouds + 1;
+    int64_t c = 0;
+    for (int64_t k = 0; k < n_clouds; k++) {
+        h_ids[k] = h_sets[k];
+        h_first[k] = (int32_t)c;
+        const int64_t nch = (h_sizes[k] + CLOUD_CHUNK - 1) / CLOUD_CHUNK;
+        for (int64_t j = 0; j < nch; j++)
+            h_cc[c++] = (int32_t)k;
+    }
+    h_first[n_clouds] = (int32_t)c;
+
+    const size_t list_bytes = (ints * sizeof(int32_t) + 15) & ~(size_t)15;
+    const size_t part_bytes = (size_t)n_chunks * PART * sizeof(double);
+    const size_t hist_bytes = (size_t)n_chunks * HIST_MAX * sizeof(uint32_t);
+    const size_t state_bytes = (size_t)n_clouds * STATE * sizeof(double);
+    unsigned char *base = (unsigned char *)fx_scratch(list_bytes + part_bytes + hist_bytes + state_bytes, 2);
+    if (!base) {
+        free(h);
+        return FX_ENOMEM;
+    }
+    hipError_t e = hipMemcpyAsync(base, h, ints * sizeof(int32_t), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(s);  // the pageable host list is freed right below
+    free(h);
+    if (e != hipSuccess) {
+        fx_set_error("fx_pca_batch_f32: uploading the chunk list failed: %s", hipGetErrorString(e));
+        return FX_EHIP;
+    }
+    CloudWork Wk;
+    Wk.cloud_ids = (const int32_t *)base;
+    Wk.cloud_first = Wk.cloud_ids + n_clouds;
+    Wk.chunk_cloud = Wk.cloud_first + n_clouds + 1;
+    Wk.part = (double *)(base + list_bytes);
+    Wk.hpart = (uint32_t *)(base + list_bytes + part_bytes);
+    Wk.state = (double *)(base + list_bytes + part_bytes + hist_bytes);
+
+    const dim3 grid((unsigned)n_chunks), block(CLOUD_THREADS);
+    hipLaunchKernelGGL(cloud_sum_kernel, grid, block, 0, s, A, Wk);
+    if (A.normalize)
+        hipLaunchKernelGGL(cloud_moment_kernel<0>, grid, block, 0, s, A, Wk);
+    hipLaunchKernelGGL(cloud_moment_kernel<1>, grid, block, 0, s, A, Wk);
+    hipLaunchKernelGGL(cloud_proj_kernel, grid, block, 0, s, A, Wk);
+    hipLaunchKernelGGL(cloud_hist_kernel, grid, block, 0, s, A, Wk);
+    hipLaunchKernelGGL(cloud_finish_kernel, dim3((unsigned)n_clouds), dim3(FX_WAVE), 0, s, A, Wk);
+    FX_HIP_CHECK(hipGetLastError());
+    return FX_OK;
 }
 
 }  // namespace
@@ -410,9 +618,22 @@ extern "C" int fx_pca_batch_f32(const float *d_pts, const int64_t *d_offsets, in
         FxProfileScope prof(s);
         if (N <= WAVE_SET_MAX_POINTS)
             return launch_small_sets(A, N < 3 ? 3 : N, s);
-        hipLaunchKernelGGL(pca_cloud_block_kernel, dim3((unsigned)B), dim3(CLOUD_BLOCK), 0, s, A);
-        FX_HIP_CHECK(hipGetLastError());
-        return FX_OK;
+        int32_t *sets = (int32_t *)malloc((size_t)B * sizeof(int32_t));
+        int64_t *sizes = (int64_t *)malloc((size_t)B * sizeof(int64_t));
+        if (!sets || !sizes) {
+            free(sets);
+            free(sizes);
+            fx_set_error("fx_pca_batch_f32: host allocation failed");
+            return FX_ENOMEM;
+        }
+        for (int64_t b = 0; b < B; b++) {
+            sets[b] = (int32_t)b;
+            sizes[b] = N;
+        }
+        const int rc = launch_large_clouds(A, sets, sizes, B, s);
+        free(sets);
+        free(sizes);
+        return rc;
     }
 
     // Ragged batch: read the offsets back once, route small sets to the LDS
@@ -436,6 +657,13 @@ extern "C" int fx_pca_batch_f32(const float *d_pts, const int64_t *d_offsets, in
         fx_set_error("fx_pca_batch_f32: host allocation failed");
         return FX_ENOMEM;
     }
+    int64_t *h_large_sizes = (int64_t *)malloc((size_t)B * sizeof(int64_t));
+    if (!h_large_sizes) {
+        free(h_off);
+        free(h_ids);
+        fx_set_error("fx_pca_batch_f32: host allocation failed");
+        return FX_ENOMEM;
+    }
     int64_t n_small = 0, n_large = 0, max_small = 3;
     bool ok = true;
     for (int64_t b = 0; b < B; b++) {
@@ -449,44 +677,48 @@ extern "C" int fx_pca_batch_f32(const float *d_pts, const int64_t *d_offsets, in
     }
     for (int64_t b = 0; b < B; b++) {
         const int64_t n = h_off[b + 1] - h_off[b];
-        if (n > WAVE_SET_MAX_POINTS)
+        if (n > WAVE_SET_MAX_POINTS) {
+            h_large_sizes[n_large] = n;
             h_ids[n_small + n_large++] = (int32_t)b;
+        }
     }
     free(h_off);
     if (!ok) {
         free(h_ids);
+        free(h_large_sizes);
         fx_set_error("fx_pca_batch_f32: offsets are not non-decreasing");
         return FX_EINVAL;
     }
-    int32_t *d_ids = (int32_t *)fx_scratch((size_t)B * sizeof(int32_t), 0);
-    if (!d_ids) {
-        free(h_ids);
-        return FX_ENOMEM;
-    }
-    e = hipMemcpyAsync(d_ids, h_ids, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess)
-        e = hipStreamSynchronize(s);  // h_ids is pageable; it is freed right below
-    free(h_ids);
-    if (e != hipSuccess) {
-        fx_set_error("fx_pca_batch_f32: uploading the work list failed: %s", hipGetErrorString(e));
-        return FX_EHIP;
+    int32_t *d_ids = nullptr;
+    if (n_small > 0) {
+        d_ids = (int32_t *)fx_scratch((size_t)n_small * sizeof(int32_t), 0);
+        if (!d_ids) {
+            free(h_ids);
+            free(h_large_sizes);
+            return FX_ENOMEM;
+        }
+        e = hipMemcpyAsync(d_ids, h_ids, (size_t)n_small * sizeof(int32_t), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(s);  // h_ids is pageable; it is freed below
+        if (e != hipSuccess) {
+            free(h_ids);
+            free(h_large_sizes);
+            fx_set_error("fx_pca_batch_f32: uploading the work list failed: %s", hipGetErrorString(e));
+            return FX_EHIP;
+        }
     }
 
     FxProfileScope prof(s);
+    int rc = FX_OK;
     if (n_small > 0) {
         PcaArgs S = A;
         S.set_ids = d_ids;
         S.n_sets = n_small;
-        int rc = launch_small_sets(S, max_small, s);
-        if (rc != FX_OK)
-            return rc;
+        rc = launch_small_sets(S, max_small, s);
     }
-    if (n_large > 0) {
-        PcaArgs L = A;
-        L.set_ids = d_ids + n_small;
-        L.n_sets = n_large;
-        hipLaunchKernelGGL(pca_cloud_block_kernel, dim3((unsigned)n_large), dim3(CLOUD_BLOCK), 0, s, L);
-        FX_HIP_CHECK(hipGetLastError());
-    }
-    return FX_OK;
+    if (rc == FX_OK && n_large > 0)
+        rc = launch_large_clouds(A, h_ids + n_small, h_large_sizes, n_large, s);
+    free(h_ids);
+    free(h_large_sizes);
+    return rc;
 }

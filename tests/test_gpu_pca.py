@@ -102,6 +102,31 @@ def test_ragged_batch_and_2d(gpu, oracle):
     assert torch.all(r2["eig"][:, 2] == 0)
 
 
+@pytest.mark.parametrize("normalize", [False, True])
+def test_variable_size_clouds_tail_config(gpu, oracle, normalize):
+    """Clouds with log-uniform sizes from 1e3 to 1.5e6 points in one ragged batch
+    (the load-imbalance configuration): small ones take the LDS kernel, large
+    ones are cut into 16384-point chunks spread over the chip."""
+    import torch
+    eng = pkg("engine")
+    rng = np.random.default_rng(31)
+    sizes = [int(v) for v in np.exp(rng.uniform(np.log(1e3), np.log(1.5e6), size=12))] + [16384, 16385, 2049, 1_200_000]
+    sets = []
+    for n in sizes:
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        sets.append(((rng.normal(size=(n, 3)) * np.array([0.9, 0.3, 0.12])) @ q.T + rng.normal(size=3)).astype(np.float32))
+    off = np.zeros(len(sizes) + 1, dtype=np.int64)
+    np.cumsum(sizes, out=off[1:])
+    flat = torch.from_numpy(np.concatenate(sets)).to(gpu)
+    res = eng.pca_batch(flat, torch.from_numpy(off).to(gpu), 8, normalize, eig=True)
+    out, eig = res["out"].cpu().numpy(), res["eig"].cpu().numpy()
+    ties = 0
+    for b, n in enumerate(sizes):
+        ref_out, ref_eig = oracle.compute_pca_features(sets[b].astype(np.float64), 8, normalize, return_eig=True)
+        ties += compare_set(out[b], eig[b], ref_out, ref_eig, n)
+    assert ties <= 3
+
+
 def test_full_size_properties(gpu):
     """C4-sized batch: invariants that need no CPU pass.  Rotating a cloud
     leaves the eigenvalues unchanged; the histogram sums to one; r1+r2+r3 = 1."""
