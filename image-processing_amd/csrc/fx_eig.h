@@ -43,23 +43,101 @@ __device__ __forceinline__ void fx_jacobi_rotate(double &app, double &aqq, doubl
     }
 }
 
+// 1/x and 1/sqrt(x) from the hardware estimate plus two Newton steps: within a
+// couple of ulps, at a fraction of the IEEE division / square-root sequences.
+__device__ __forceinline__ double fx_rcp_nr(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(r, fma(-x, r, 1.0), r);
+    r = fma(r, fma(-x, r, 1.0), r);
+    return r;
+}
+__device__ __forceinline__ double fx_rsq_nr(double x)
+{
+    double r = __builtin_amdgcn_rsq(x);
+    r = fma(r * 0.5, fma(-x * r, r, 1.0), r);
+    r = fma(r * 0.5, fma(-x * r, r, 1.0), r);
+    return r;
+}
+
+// The same rotation with Newton-refined reciprocals.  A rotation only has to
+// be orthogonal to rounding level (c^2 + s^2 = 1 +- a few ulps) and to shrink
+// a_pq; the last bits of the angle do not matter to the converged result.
+__device__ __forceinline__ void fx_jacobi_rotate_fast(double &app, double &aqq, double &apq, double &arp,
+                                                      double &arq, double (&V)[3][3], int p, int q)
+{
+    if (apq == 0.0)
+        return;
+    const double d = aqq - app;
+    const double two = apq + apq;
+    const double h2 = fma(d, d, two * two);
+    const double h = h2 * fx_rsq_nr(h2);
+    double t = two * fx_rcp_nr(fabs(d) + h);
+    if (d < 0.0)
+        t = -t;
+    const double c = fx_rsq_nr(fma(t, t, 1.0));
+    const double s = t * c;
+    const double tap = t * apq;
+    app = app - tap;
+    aqq = aqq + tap;
+    apq = 0.0;
+    const double np_ = c * arp - s * arq;
+    const double nq_ = s * arp + c * arq;
+    arp = np_;
+    arq = nq_;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const double vp = V[k][p], vq = V[k][q];
+        V[k][p] = c * vp - s * vq;
+        V[k][q] = s * vp + c * vq;
+    }
+}
+
 // Eigenvalues (descending) and the eigenvector of the largest one of the
 // symmetric matrix [[a00 a01 a02][a01 a11 a12][a02 a12 a22]] by cyclic Jacobi
 // sweeps.  A coordinate that is exactly uncoupled (its off-diagonal entries are
 // 0.0, e.g. z of a planar set) keeps its diagonal entry unchanged, so a planar
 // set gets an exact 0.0 eigenvalue as LAPACK's eigh returns for it.
+// FAST: Newton-refined reciprocals in the rotations and the matrix scaled to
+// unit magnitude first (so that squares cannot leave the double range); used
+// where the solve sits on the critical path of a streaming kernel.
+template <bool FAST = false>
 __device__ __forceinline__ void fx_eig3(double a00, double a01, double a02, double a11, double a12,
                                         double a22, double (&lam)[3], double (&v1)[3])
 {
     double V[3][3] = {{1.0, 0.0, 0.0}, {0.0, 1.0, 0.0}, {0.0, 0.0, 1.0}};
+    int scale_exp = 0;
+    if (FAST) {
+        const double big = fmax(fmax(fabs(a00), fabs(a11)), fabs(a22));
+        if (big > 0.0 && big < 1.7e308) {
+            (void)frexp(big, &scale_exp);
+            a00 = ldexp(a00, -scale_exp);
+            a01 = ldexp(a01, -scale_exp);
+            a02 = ldexp(a02, -scale_exp);
+            a11 = ldexp(a11, -scale_exp);
+            a12 = ldexp(a12, -scale_exp);
+            a22 = ldexp(a22, -scale_exp);
+        }
+    }
     for (int sweep = 0; sweep < 12; sweep++) {
         double off = fabs(a01) + fabs(a02) + fabs(a12);
         double diag = fabs(a00) + fabs(a11) + fabs(a22);
         if (off == 0.0 || off <= 1e-19 * diag)
             break;
-        fx_jacobi_rotate(a00, a11, a01, a02, a12, V, 0, 1);
-        fx_jacobi_rotate(a00, a22, a02, a01, a12, V, 0, 2);
-        fx_jacobi_rotate(a11, a22, a12, a01, a02, V, 1, 2);
+        if (FAST) {
+            fx_jacobi_rotate_fast(a00, a11, a01, a02, a12, V, 0, 1);
+            fx_jacobi_rotate_fast(a00, a22, a02, a01, a12, V, 0, 2);
+            fx_jacobi_rotate_fast(a11, a22, a12, a01, a02, V, 1, 2);
+        } else {
+            fx_jacobi_rotate(a00, a11, a01, a02, a12, V, 0, 1);
+            fx_jacobi_rotate(a00, a22, a02, a01, a12, V, 0, 2);
+            fx_jacobi_rotate(a11, a22, a12, a01, a02, V, 1, 2);
+        }
+    }
+    if (FAST && scale_exp != 0) {
+        a00 = ldexp(a00, scale_exp);
+        a11 = ldexp(a11, scale_exp);
+        a22 = ldexp(a22, scale_exp);
     }
     double w0 = a00, w1 = a11, w2 = a22;
     int i0 = 0, i1 = 1, i2 = 2;

@@ -64,11 +64,12 @@ __device__ __forceinline__ void write_nan_row(const PcaArgs &A, int64_t set, int
 
 // Everything after the second-moment sums: covariance scaling exactly as
 // np.cov does (multiply by 1/(n-1)), eigen-decomposition, the nine scalars.
+template <bool FAST = false>
 __device__ __forceinline__ void cov_to_head(const double (&S)[6], int64_t n, double (&head)[9], double (&lam)[3],
                                             double (&v1)[3])
 {
     const double inv = 1.0 / (double)(n - 1);
-    fx_eig3(S[0] * inv, S[1] * inv, S[2] * inv, S[3] * inv, S[4] * inv, S[5] * inv, lam, v1);
+    fx_eig3<FAST>(S[0] * inv, S[1] * inv, S[2] * inv, S[3] * inv, S[4] * inv, S[5] * inv, lam, v1);
     fx_pca_head(lam, head);
 }
 
@@ -122,17 +123,42 @@ __global__ __launch_bounds__(FX_WAVE *WPB) void pca_sets_wave_kernel(PcaArgs A)
     auto py = [&](int i) -> double { return (double)slab[i * dims + 1]; };
     auto pz = [&](int i) -> double { return dims == 3 ? (double)slab[i * dims + 2] : 0.0; };
 
-    // ---- mean ---------------------------------------------------------------
-    double sx = 0.0, sy = 0.0, sz = 0.0;
+    // ---- one pass: first and second moments about a pivot -------------------
+    // The pivot is the set's first point, so the shifted coordinates are of the
+    // size of the spread and S = sum d d^T - (sum d)(sum d)^T / n loses nothing
+    // at float64 (the inputs are float32).
+    const float kx32 = slab[0], ky32 = slab[1], kz32 = dims == 3 ? slab[2] : 0.0f;
+    const double kx = kx32, ky = ky32, kz = kz32;
+    double D[3] = {0, 0, 0}, Q[6] = {0, 0, 0, 0, 0, 0};
     for (int i = lane; i < n; i += FX_WAVE) {
-        sx += px(i);
-        sy += py(i);
-        sz += pz(i);
+        const double dx = px(i) - kx, dy = py(i) - ky, dz = pz(i) - kz;
+        D[0] += dx;
+        D[1] += dy;
+        D[2] += dz;
+        Q[0] = fma(dx, dx, Q[0]);
+        Q[1] = fma(dx, dy, Q[1]);
+        Q[2] = fma(dx, dz, Q[2]);
+        Q[3] = fma(dy, dy, Q[3]);
+        Q[4] = fma(dy, dz, Q[4]);
+        Q[5] = fma(dz, dz, Q[5]);
     }
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        D[k] = fx_wave_sum_f64(D[k]);
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+        Q[k] = fx_wave_sum_f64(Q[k]);
     const double dn = (double)n;
-    const double mx = fx_wave_sum_f64(sx) / dn;
-    const double my = fx_wave_sum_f64(sy) / dn;
-    const double mz = fx_wave_sum_f64(sz) / dn;
+    const double inv_n = 1.0 / dn;
+    const double ox = D[0] * inv_n, oy = D[1] * inv_n, oz = D[2] * inv_n;  // mean - pivot
+    const double mx = kx + ox, my = ky + oy, mz = kz + oz;
+    double S[6];
+    S[0] = fma(-D[0], ox, Q[0]);
+    S[1] = fma(-D[0], oy, Q[1]);
+    S[2] = fma(-D[0], oz, Q[2]);
+    S[3] = fma(-D[1], oy, Q[3]);
+    S[4] = fma(-D[1], oz, Q[4]);
+    S[5] = fma(-D[2], oz, Q[5]);
 
     // ---- optional normalisation by the largest centred norm ----------------
     double rmax = 0.0;
@@ -145,32 +171,19 @@ __global__ __launch_bounds__(FX_WAVE *WPB) void pca_sets_wave_kernel(PcaArgs A)
         rmax = sqrt(fx_wave_max_f64(r2));
     }
     const bool scale = A.normalize && rmax > 0.0;
-
-    // ---- centred second moments --------------------------------------------
-    double S[6] = {0, 0, 0, 0, 0, 0};
-    for (int i = lane; i < n; i += FX_WAVE) {
-        double dx = px(i) - mx, dy = py(i) - my, dz = pz(i) - mz;
-        if (scale) {
-            dx /= rmax;
-            dy /= rmax;
-            dz /= rmax;
-        }
-        S[0] = fma(dx, dx, S[0]);
-        S[1] = fma(dx, dy, S[1]);
-        S[2] = fma(dx, dz, S[2]);
-        S[3] = fma(dy, dy, S[3]);
-        S[4] = fma(dy, dz, S[4]);
-        S[5] = fma(dz, dz, S[5]);
-    }
+    if (scale) {
+        const double w = 1.0 / (rmax * rmax);
 #pragma unroll
-    for (int k = 0; k < 6; k++)
-        S[k] = fx_wave_sum_f64(S[k]);
+        for (int k = 0; k < 6; k++)
+            S[k] *= w;
+    }
 
     // every lane holds the same sums and runs the same eigen-solve
     double head[9], lam[3], v1[3];
-    cov_to_head(S, n, head, lam, v1);
+    cov_to_head<true>(S, n, head, lam, v1);
 
     // ---- |projection on PC1|: maximum, then histogram ----------------------
+    // float64 value of a point (the formula of record)
     auto proj = [&](int i) -> double {
         double dx = px(i) - mx, dy = py(i) - my, dz = pz(i) - mz;
         if (scale) {
@@ -180,9 +193,28 @@ __global__ __launch_bounds__(FX_WAVE *WPB) void pca_sets_wave_kernel(PcaArgs A)
         }
         return fabs(fma(dz, v1[2], fma(dy, v1[1], dx * v1[0])));
     };
+    // float32 value: pivot-relative coordinates keep its error at the scale of
+    // the spread, eps32 bounds it generously.  It settles everything that is not
+    // within eps32 of a decision; those few points are decided in float64.
+    const float ox32 = (float)ox, oy32 = (float)oy, oz32 = (float)oz;
+    const float w32 = scale ? (float)(1.0 / rmax) : 1.0f;
+    const float vx32 = (float)v1[0] * w32, vy32 = (float)v1[1] * w32, vz32 = (float)v1[2] * w32;
+    auto proj32 = [&](int i) -> float {
+        const float dx = (slab[i * dims] - kx32) - ox32, dy = (slab[i * dims + 1] - ky32) - oy32;
+        const float dz = dims == 3 ? (slab[i * dims + 2] - kz32) - oz32 : -oz32;
+        return fabsf(fmaf(dz, vz32, fmaf(dy, vy32, dx * vx32)));
+    };
+    float top32 = 0.0f;
+    for (int i = lane; i < n; i += FX_WAVE)
+        top32 = fmaxf(top32, proj32(i));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        top32 = fmaxf(top32, __shfl_xor(top32, o, FX_WAVE));
+    const float eps32 = 2e-6f * (top32 + (fabsf(ox32) + fabsf(oy32) + fabsf(oz32)) * w32) + 1e-37f;
     double top = 0.0;
     for (int i = lane; i < n; i += FX_WAVE)
-        top = fmax(top, proj(i));
+        if (proj32(i) >= top32 - 2.0f * eps32)  // the exact maximum is among these
+            top = fmax(top, proj(i));
     top = fx_wave_max_f64(top);
 
     const int nb = A.n_bins;
@@ -190,8 +222,19 @@ __global__ __launch_bounds__(FX_WAVE *WPB) void pca_sets_wave_kernel(PcaArgs A)
     if (top > 0.0) {
         const double step = top / (double)nb;
         const double inv_step = (double)nb / top;
-        for (int i = lane; i < n; i += FX_WAVE)
-            atomicAdd(&hist[fx_hist_bin(proj(i), step, inv_step, nb)], 1u);
+        const float inv32 = (float)inv_step;
+        const float margin = 2.0f * eps32 * inv32 + 1e-5f * (float)nb;
+        for (int i = lane; i < n; i += FX_WAVE) {
+            const float q = proj32(i) * inv32;
+            const float f = floorf(q);
+            const float frac = q - f;
+            int bin;
+            if (frac < margin || frac > 1.0f - margin || q >= (float)nb)
+                bin = fx_hist_bin(proj(i), step, inv_step, nb);
+            else
+                bin = (int)f;
+            atomicAdd(&hist[bin], 1u);
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (lane < nb)
