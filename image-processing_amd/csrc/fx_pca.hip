@@ -12,6 +12,8 @@
 // passes (sum, centred second moments, projection maximum, histogram).
 #include "fx_common.h"
 #include "fx_eig.h"
+#include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -234,6 +236,188 @@ __global__ __launch_bounds__(FX_WAVE *WPB) void pca_sets_wave_kernel(PcaArgs A)
             else
                 bin = (int)f;
             atomicAdd(&hist[bin], 1u);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < nb)
+            A.out[set * width + 9 + lane] = (float)((double)hist[lane] / dn);
+    } else if (lane < nb) {
+        A.out[set * width + 9 + lane] = lane == 0 ? 1.0f : 0.0f;
+    }
+    if (lane < 9) {
+        double h = head[0];
+#pragma unroll
+        for (int k = 1; k < 9; k++)
+            h = lane == k ? head[k] : h;
+        A.out[set * width + lane] = (float)h;
+    }
+    if (A.eig && lane < 6) {
+        double e = lam[0];
+        e = lane == 1 ? lam[1] : e;
+        e = lane == 2 ? lam[2] : e;
+        e = lane == 3 ? v1[0] : e;
+        e = lane == 4 ? v1[1] : e;
+        e = lane == 5 ? v1[2] : e;
+        A.eig[set * 6 + lane] = e;
+    }
+}
+
+// ------------------------------------------------------- register-resident sets
+// Equal-sized sets of up to 64 * PPL points (the pipeline's 1024-point clouds:
+// PPL = 16): every lane loads 4-point groups (48 contiguous bytes, three 16-byte
+// loads) straight into registers and keeps its points there for all passes, so
+// the kernel needs no LDS slab, runs at register-limited occupancy and the
+// passes are straight-line code over PPL independent points.  Same arithmetic
+// as pca_sets_wave_kernel.
+#ifndef FX_PCA_WAVES
+#define FX_PCA_WAVES 4
+#endif
+template <int PPL>
+__global__ __launch_bounds__(FX_BLOCK, FX_PCA_WAVES) void pca_sets_reg_kernel(PcaArgs A)
+{
+    __shared__ uint32_t hist_all[FX_WAVES_PER_BLOCK][HIST_MAX];
+    const int lane = fx_lane(), wave = fx_wave();
+    const int64_t set = (int64_t)blockIdx.x * FX_WAVES_PER_BLOCK + wave;
+    if (set >= A.n_sets)
+        return;  // whole wave leaves; no block-level barrier is used below
+    const int n = (int)A.N;
+    uint32_t *hist = hist_all[wave];
+    hist[lane] = 0;
+
+    constexpr int G = PPL / 4;  // 4-point groups per lane
+    const float4 *g4 = reinterpret_cast<const float4 *>(A.pts + set * (int64_t)n * 3);
+    float x[PPL], y[PPL], z[PPL];
+    bool have[G];
+#pragma unroll
+    for (int k = 0; k < G; k++) {
+        const int grp = lane + FX_WAVE * k;  // points 4*grp .. 4*grp+3
+        have[k] = 4 * grp < n;               // n is a multiple of 4
+        const int gc = have[k] ? grp : 0;
+        const float4 a = g4[3 * gc], b = g4[3 * gc + 1], c = g4[3 * gc + 2];
+        x[4 * k] = a.x, y[4 * k] = a.y, z[4 * k] = a.z;
+        x[4 * k + 1] = a.w, y[4 * k + 1] = b.x, z[4 * k + 1] = b.y;
+        x[4 * k + 2] = b.z, y[4 * k + 2] = b.w, z[4 * k + 2] = c.x;
+        x[4 * k + 3] = c.y, y[4 * k + 3] = c.z, z[4 * k + 3] = c.w;
+    }
+    // pivot = the set's first point (lane 0, group 0)
+    const float kx32 = __shfl(x[0], 0, FX_WAVE), ky32 = __shfl(y[0], 0, FX_WAVE), kz32 = __shfl(z[0], 0, FX_WAVE);
+    const double kx = kx32, ky = ky32, kz = kz32;
+
+    double D[3] = {0, 0, 0}, Q[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < PPL; i++) {
+        if (have[i >> 2]) {
+            const double dx = (double)x[i] - kx, dy = (double)y[i] - ky, dz = (double)z[i] - kz;
+            D[0] += dx;
+            D[1] += dy;
+            D[2] += dz;
+            Q[0] = fma(dx, dx, Q[0]);
+            Q[1] = fma(dx, dy, Q[1]);
+            Q[2] = fma(dx, dz, Q[2]);
+            Q[3] = fma(dy, dy, Q[3]);
+            Q[4] = fma(dy, dz, Q[4]);
+            Q[5] = fma(dz, dz, Q[5]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        D[k] = fx_wave_sum_f64(D[k]);
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+        Q[k] = fx_wave_sum_f64(Q[k]);
+    const double dn = (double)n;
+    const double inv_n = 1.0 / dn;
+    const double ox = D[0] * inv_n, oy = D[1] * inv_n, oz = D[2] * inv_n;  // mean - pivot
+    const double mx = kx + ox, my = ky + oy, mz = kz + oz;
+    double S[6];
+    S[0] = fma(-D[0], ox, Q[0]);
+    S[1] = fma(-D[0], oy, Q[1]);
+    S[2] = fma(-D[0], oz, Q[2]);
+    S[3] = fma(-D[1], oy, Q[3]);
+    S[4] = fma(-D[1], oz, Q[4]);
+    S[5] = fma(-D[2], oz, Q[5]);
+
+    double rmax = 0.0;
+    if (A.normalize) {
+        double r2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < PPL; i++) {
+            if (have[i >> 2]) {
+                const double dx = (double)x[i] - mx, dy = (double)y[i] - my, dz = (double)z[i] - mz;
+                r2 = fmax(r2, dx * dx + dy * dy + dz * dz);
+            }
+        }
+        rmax = sqrt(fx_wave_max_f64(r2));
+    }
+    const bool scale = A.normalize && rmax > 0.0;
+    if (scale) {
+        const double w = 1.0 / (rmax * rmax);
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+            S[k] *= w;
+    }
+
+    // every lane holds the same sums and runs the same eigen-solve
+    double head[9], lam[3], v1[3];
+    cov_to_head<true>(S, n, head, lam, v1);
+
+    // float64 value of a point (the formula of record)
+    auto proj = [&](float px, float py, float pz) -> double {
+        double dx = (double)px - mx, dy = (double)py - my, dz = (double)pz - mz;
+        if (scale) {
+            dx /= rmax;
+            dy /= rmax;
+            dz /= rmax;
+        }
+        return fabs(fma(dz, v1[2], fma(dy, v1[1], dx * v1[0])));
+    };
+    // float32 value, pivot-relative so that its error is at the scale of the
+    // spread; eps32 bounds it generously.  It settles every point that is not
+    // within eps32 of a decision; those few are decided in float64.
+    const float ox32 = (float)ox, oy32 = (float)oy, oz32 = (float)oz;
+    const float w32 = scale ? (float)(1.0 / rmax) : 1.0f;
+    const float vx32 = (float)v1[0] * w32, vy32 = (float)v1[1] * w32, vz32 = (float)v1[2] * w32;
+    float p32[PPL];
+    float top32 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < PPL; i++) {
+        const float dx = (x[i] - kx32) - ox32, dy = (y[i] - ky32) - oy32, dz = (z[i] - kz32) - oz32;
+        p32[i] = have[i >> 2] ? fabsf(fmaf(dz, vz32, fmaf(dy, vy32, dx * vx32))) : -1.0f;
+        top32 = fmaxf(top32, p32[i]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        top32 = fmaxf(top32, __shfl_xor(top32, o, FX_WAVE));
+    const float eps32 = 2e-6f * (top32 + (fabsf(ox32) + fabsf(oy32) + fabsf(oz32)) * w32) + 1e-37f;
+    double top = 0.0;
+#pragma unroll
+    for (int i = 0; i < PPL; i++)
+        if (p32[i] >= top32 - 2.0f * eps32)  // the exact maximum is among these
+            top = fmax(top, proj(x[i], y[i], z[i]));
+    top = fx_wave_max_f64(top);
+
+    const int nb = A.n_bins;
+    const int width = 9 + nb;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (top > 0.0) {
+        const double step = top / (double)nb;
+        const double inv_step = (double)nb / top;
+        const float inv32 = (float)inv_step;
+        const float margin = 2.0f * eps32 * inv32 + 1e-5f * (float)nb;
+#pragma unroll
+        for (int i = 0; i < PPL; i++) {
+            if (have[i >> 2]) {
+                const float q = p32[i] * inv32;
+                const float f = floorf(q);
+                const float frac = q - f;
+                int bin;
+                if (frac < margin || frac > 1.0f - margin || q >= (float)nb)
+                    bin = fx_hist_bin(proj(x[i], y[i], z[i]), step, inv_step, nb);
+                else
+                    bin = (int)f;
+                atomicAdd(&hist[bin], 1u);
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -659,6 +843,20 @@ extern "C" int fx_pca_batch_f32(const float *d_pts, const int64_t *d_offsets, in
 
     if (!d_offsets) {
         FxProfileScope prof(s);
+        const char *force = getenv("FX_PCA_KERNEL");  // "lds": development switch
+        const bool reg_ok = dims == 3 && N >= 4 && N <= 1024 && N % 4 == 0 && (uintptr_t)d_pts % 16 == 0 &&
+                            !(force && strcmp(force, "lds") == 0);
+        if (reg_ok) {
+            const dim3 grid((unsigned)((B + FX_WAVES_PER_BLOCK - 1) / FX_WAVES_PER_BLOCK)), block(FX_BLOCK);
+            if (N <= 256)
+                hipLaunchKernelGGL(pca_sets_reg_kernel<4>, grid, block, 0, s, A);
+            else if (N <= 512)
+                hipLaunchKernelGGL(pca_sets_reg_kernel<8>, grid, block, 0, s, A);
+            else
+                hipLaunchKernelGGL(pca_sets_reg_kernel<16>, grid, block, 0, s, A);
+            FX_HIP_CHECK(hipGetLastError());
+            return FX_OK;
+        }
         if (N <= WAVE_SET_MAX_POINTS)
             return launch_small_sets(A, N < 3 ? 3 : N, s);
         int32_t *sets = (int32_t *)malloc((size_t)B * sizeof(int32_t));

@@ -98,8 +98,11 @@ def test_ragged_batch_and_2d(gpu, oracle):
     r2 = eng.pca_batch(torch.from_numpy(p2).to(gpu), None, 8, False, eig=True)
     p3 = np.concatenate([p2, np.zeros((4, 500, 1), np.float32)], axis=2)
     r3 = eng.pca_batch(torch.from_numpy(p3).to(gpu), None, 8, False, eig=True)
-    assert torch.equal(r2["out"], r3["out"]) and torch.equal(r2["eig"], r3["eig"])
-    assert torch.all(r2["eig"][:, 2] == 0)
+    # the 2-D call runs the LDS kernel, the 3-D one the register kernel: same values up to summation order
+    assert torch.allclose(r2["out"], r3["out"], rtol=1e-6, atol=0)
+    assert torch.allclose(r2["eig"][:, :3], r3["eig"][:, :3], rtol=1e-12, atol=0)
+    assert torch.all((r2["eig"][:, 3:] * r3["eig"][:, 3:]).sum(dim=1).abs() > 1 - 1e-12)
+    assert torch.all(r2["eig"][:, 2] == 0) and torch.all(r3["eig"][:, 2] == 0)
 
 
 @pytest.mark.parametrize("normalize", [False, True])
