@@ -272,7 +272,8 @@ __global__ __launch_bounds__(FX_WAVE *WPB) void pca_sets_wave_kernel(PcaArgs A)
 #ifndef FX_PCA_WAVES
 #define FX_PCA_WAVES 4
 #endif
-template <int PPL>
+// FULL: the set has exactly 64 * PPL points, no lane holds a missing point.
+template <int PPL, bool FULL>
 __global__ __launch_bounds__(FX_BLOCK, FX_PCA_WAVES) void pca_sets_reg_kernel(PcaArgs A)
 {
     __shared__ uint32_t hist_all[FX_WAVES_PER_BLOCK][HIST_MAX];
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(FX_BLOCK, FX_PCA_WAVES) void pca_sets_reg_kernel(Pc
 #pragma unroll
     for (int k = 0; k < G; k++) {
         const int grp = lane + FX_WAVE * k;  // points 4*grp .. 4*grp+3
-        have[k] = 4 * grp < n;               // n is a multiple of 4
+        have[k] = FULL || 4 * grp < n;       // n is a multiple of 4
         const int gc = have[k] ? grp : 0;
         const float4 a = g4[3 * gc], b = g4[3 * gc + 1], c = g4[3 * gc + 2];
         x[4 * k] = a.x, y[4 * k] = a.y, z[4 * k] = a.z;
@@ -358,8 +359,25 @@ __global__ __launch_bounds__(FX_BLOCK, FX_PCA_WAVES) void pca_sets_reg_kernel(Pc
     }
 
     // every lane holds the same sums and runs the same eigen-solve
-    double head[9], lam[3], v1[3];
-    cov_to_head<true>(S, n, head, lam, v1);
+    double lam[3], v1[3];
+    {
+        const double inv = 1.0 / (double)(n - 1);  // np.cov multiplies by 1/(n-1)
+        fx_eig3<true>(S[0] * inv, S[1] * inv, S[2] * inv, S[3] * inv, S[4] * inv, S[5] * inv, lam, v1);
+    }
+    // the nine scalars (fx_pca_head), lane k computing entry k: one division
+    // per lane instead of five one after the other
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+        lam[q] = lam[q] < 0.0 ? 0.0 : lam[q];
+    const double trace = lam[0] + lam[1] + lam[2];
+    double head_mine;
+    {
+        const double safe = trace > 1e-12 ? trace : 1e-12;
+        const int e = lane < 9 ? lane : 0;
+        const double num = (e == 0 || e == 3 || e == 6) ? lam[0] : (e == 1 || e == 4 || e == 7) ? lam[1] : (e == 2 || e == 5) ? lam[2] : trace;
+        const double den = e < 3 || e == 8 ? 1.0 : e < 6 ? safe : e == 6 ? lam[1] + 1e-12 : lam[2] + 1e-12;
+        head_mine = num / den;
+    }
 
     // float64 value of a point (the formula of record)
     auto proj = [&](float px, float py, float pz) -> double {
@@ -405,17 +423,17 @@ __global__ __launch_bounds__(FX_BLOCK, FX_PCA_WAVES) void pca_sets_reg_kernel(Pc
         const double inv_step = (double)nb / top;
         const float inv32 = (float)inv_step;
         const float margin = 2.0f * eps32 * inv32 + 1e-5f * (float)nb;
+        const float qmax = (float)nb - margin;
 #pragma unroll
         for (int i = 0; i < PPL; i++) {
             if (have[i >> 2]) {
+                // q within `margin` of an integer (a bin edge), or at the top edge: float64 decides
                 const float q = p32[i] * inv32;
-                const float f = floorf(q);
-                const float frac = q - f;
                 int bin;
-                if (frac < margin || frac > 1.0f - margin || q >= (float)nb)
+                if (fabsf(q - rintf(q)) < margin || q >= qmax)
                     bin = fx_hist_bin(proj(x[i], y[i], z[i]), step, inv_step, nb);
                 else
-                    bin = (int)f;
+                    bin = (int)q;
                 atomicAdd(&hist[bin], 1u);
             }
         }
@@ -426,13 +444,8 @@ __global__ __launch_bounds__(FX_BLOCK, FX_PCA_WAVES) void pca_sets_reg_kernel(Pc
     } else if (lane < nb) {
         A.out[set * width + 9 + lane] = lane == 0 ? 1.0f : 0.0f;
     }
-    if (lane < 9) {
-        double h = head[0];
-#pragma unroll
-        for (int k = 1; k < 9; k++)
-            h = lane == k ? head[k] : h;
-        A.out[set * width + lane] = (float)h;
-    }
+    if (lane < 9)
+        A.out[set * width + lane] = (float)head_mine;
     if (A.eig && lane < 6) {
         double e = lam[0];
         e = lane == 1 ? lam[1] : e;
@@ -849,11 +862,11 @@ extern "C" int fx_pca_batch_f32(const float *d_pts, const int64_t *d_offsets, in
         if (reg_ok) {
             const dim3 grid((unsigned)((B + FX_WAVES_PER_BLOCK - 1) / FX_WAVES_PER_BLOCK)), block(FX_BLOCK);
             if (N <= 256)
-                hipLaunchKernelGGL(pca_sets_reg_kernel<4>, grid, block, 0, s, A);
+                hipLaunchKernelGGL((pca_sets_reg_kernel<4, false>), grid, block, 0, s, A);
             else if (N <= 512)
-                hipLaunchKernelGGL(pca_sets_reg_kernel<8>, grid, block, 0, s, A);
+                hipLaunchKernelGGL((pca_sets_reg_kernel<8, false>), grid, block, 0, s, A);
             else
-                hipLaunchKernelGGL(pca_sets_reg_kernel<16>, grid, block, 0, s, A);
+                hipLaunchKernelGGL((pca_sets_reg_kernel<16, false>), grid, block, 0, s, A);
             FX_HIP_CHECK(hipGetLastError());
             return FX_OK;
         }
