@@ -191,12 +191,12 @@ def main():
                        "bytes_per_unit": wl["bytes_per_unit"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": {"pca": "pca_sets_wave_kernel", "hu": "hu_band_kernel", "hu+cpca": "hu_band_kernel"}[kind],
+                         "kernel": {"pca": "pca_sets_reg_kernel", "hu": "hu_band_kernel", "hu+cpca": "hu_band_kernel"}[kind],
                          "kernel_ms": kavg, "units_per_launch": units},
         }
         if world == 1 and not args.no_cpu_baseline:
             cores = min(16, os.cpu_count() or 1)
-            n_s = args.cpu_sample or (cores * (10000 if kind == "pca" else (1800 if kind == "hu+cpca" else 6000)))
+            n_s = args.cpu_sample or (cores * (12000 if kind == "pca" else (2400 if kind == "hu+cpca" else 12000)))
             n_s = min(n_s, units)
             sample = data[:n_s].cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(kind, sample, cores)
