@@ -1,0 +1,712 @@
+// libfx: silhouette preprocessing of gray views, the step in front of the Hu
+// moments (reference src/features/extract_2d_hu.py: compute_otsu :129-188,
+// find_largest_bbox :191-221, clean_mask_np :246-346, preprocess_image
+// :352-440 -- the branch the reference takes when OpenCV is not installed:
+// PIL GaussianBlur(radius=1), NumPy Otsu, scipy.ndimage 3x3 closing/opening,
+// bounding-box crop, PIL nearest resize, 3x3 opening, 4-connected component
+// size filter, centred paste).  Everything is integer or bit work except the
+// Otsu criterion and the resize geometry, which are IEEE float64 in the
+// reference's operation order.
+//
+//   sil_blur_kernel   a block per 32-row tile: the six 3-tap passes of PIL's
+//                     radius-1 Gaussian (three along x in registers, three
+//                     along y from an LDS tile), blurred bytes + 256-bin
+//                     histogram to scratch.
+//   sil_mask_kernel   a block per image: Otsu level, bit mask (32 pixels per
+//                     word) in LDS, bit-parallel morphology, crop geometry,
+//                     nearest resize, run-based union-find labelling, size
+//                     filter, 0/255 canvas.
+#include "fx_common.h"
+
+namespace {
+
+constexpr int SIL_TR = 32;    // output rows per blur tile
+constexpr int SIL_HALO = 3;   // three 3-tap passes
+constexpr int SIL_TROWS = SIL_TR + 2 * SIL_HALO;
+constexpr int SIL_MAX_SIDE = 512;
+constexpr int SIL_RUNS_LDS = 2048;  // run table kept in LDS up to this many runs
+constexpr int SIL_MAX_GRID = 1536;
+
+// PIL's box blur for GaussianBlur(radius=1): three passes of a box of radius
+// 0.25, i.e. taps (fw, ww, fw) / 2^24 with ww = uint32(float32(2^24) /
+// float32(1.5)) and fw = (2^24 - ww) / 2, rounded to uint8 after every pass,
+// edge pixels replicated.
+constexpr uint32_t SIL_WW = 11184811u;
+constexpr uint32_t SIL_FW = 2796202u;
+
+struct SilArgs {
+    const uint8_t *img;
+    int64_t B;
+    int H, W;
+    int64_t pitch, stride;
+    int res;
+    double crop_margin;
+    int crop;
+    int min_size;
+    uint8_t *mask;    // [B][res][res]
+    int32_t *info;    // [B][8] or null
+    uint8_t *blur;    // [B][H][W]
+    uint32_t *hist;   // [B][256]
+    uint32_t *runs;   // [grid][2 * run_cap], used when a mask has more than SIL_RUNS_LDS runs
+    int run_cap;
+    int wpr;          // words per row of the LDS masks
+    int rows;         // rows of the LDS masks
+};
+
+__device__ __forceinline__ uint32_t sil_tap(uint32_t l, uint32_t c, uint32_t r)
+{
+    return (c * SIL_WW + (l + r) * SIL_FW + (1u << 23)) >> 24;
+}
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(FX_BLOCK) void sil_blur_kernel(SilArgs A)
+{
+    extern __shared__ __align__(16) uint8_t sil_smem[];
+    const int Wp = (A.W + 15) & ~15;
+    uint8_t *tile = sil_smem;                                    // [SIL_TROWS][Wp]
+    uint32_t *hist = (uint32_t *)(sil_smem + SIL_TROWS * Wp);    // [256]
+    const int64_t b = blockIdx.y;
+    const int r0 = blockIdx.x * SIL_TR;
+    const uint8_t *src = A.img + b * A.stride;
+    const int cpr = Wp >> 4;
+    hist[threadIdx.x] = 0;
+    // tile row i holds image row r0 - SIL_HALO + i; rows [ilo, ihi] exist
+    const int ilo = SIL_HALO - r0 > 0 ? SIL_HALO - r0 : 0;
+    const int ihi = A.H - 1 - r0 + SIL_HALO < SIL_TROWS - 1 ? A.H - 1 - r0 + SIL_HALO : SIL_TROWS - 1;
+
+    // three passes along x: 16 pixels + 3 on each side in registers
+    for (int it = threadIdx.x; it < SIL_TROWS * cpr; it += FX_BLOCK) {
+        const int i = it / cpr, c = it - i * cpr;
+        if (i < ilo || i > ihi)
+            continue;
+        const uint8_t *row = src + (int64_t)(r0 - SIL_HALO + i) * A.pitch;
+        const int x0 = c * 16;
+        uint32_t v[22];
+        if (ALIGNED) {
+            const uint4 m = *(const uint4 *)(row + x0);
+            const uint32_t l = x0 > 0 ? *(const uint32_t *)(row + x0 - 4) : 0u;
+            const uint32_t r = x0 + 16 < A.W ? *(const uint32_t *)(row + x0 + 16) : 0u;
+            v[0] = (l >> 8) & 255u;
+            v[1] = (l >> 16) & 255u;
+            v[2] = l >> 24;
+            const uint32_t mw[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                v[3 + k] = (mw[k >> 2] >> (8 * (k & 3))) & 255u;
+            v[19] = r & 255u;
+            v[20] = (r >> 8) & 255u;
+            v[21] = (r >> 16) & 255u;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 22; k++) {
+                int x = x0 - 3 + k;
+                x = x < 0 ? 0 : (x > A.W - 1 ? A.W - 1 : x);
+                v[k] = row[x];
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            uint32_t n[22];
+#pragma unroll
+            for (int k = 1 + p; k <= 20 - p; k++) {
+                const int x = x0 - 3 + k;
+                // the neighbour of an edge pixel is the pixel itself
+                const uint32_t l = x - 1 < 0 ? v[k] : v[k - 1];
+                const uint32_t r = x + 1 > A.W - 1 ? v[k] : v[k + 1];
+                n[k] = sil_tap(l, v[k], r);
+            }
+#pragma unroll
+            for (int k = 1 + p; k <= 20 - p; k++)
+                v[k] = n[k];
+        }
+        uint4 o;
+        o.x = v[3] | (v[4] << 8) | (v[5] << 16) | (v[6] << 24);
+        o.y = v[7] | (v[8] << 8) | (v[9] << 16) | (v[10] << 24);
+        o.z = v[11] | (v[12] << 8) | (v[13] << 16) | (v[14] << 24);
+        o.w = v[15] | (v[16] << 8) | (v[17] << 16) | (v[18] << 24);
+        *(uint4 *)(tile + i * Wp + x0) = o;
+    }
+    __syncthreads();
+
+    // three passes along y: a thread per column, the column in registers
+    uint8_t *dst = A.blur + b * (int64_t)A.H * A.W;
+    for (int x = threadIdx.x; x < A.W; x += FX_BLOCK) {
+        uint32_t c[SIL_TROWS];
+#pragma unroll
+        for (int i = 0; i < SIL_TROWS; i++)
+            c[i] = tile[i * Wp + x];
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            uint32_t n[SIL_TROWS];
+#pragma unroll
+            for (int i = 1 + p; i <= SIL_TROWS - 2 - p; i++) {
+                const uint32_t up = i - 1 < ilo ? c[i] : c[i - 1];
+                const uint32_t dn = i + 1 > ihi ? c[i] : c[i + 1];
+                n[i] = sil_tap(up, c[i], dn);
+            }
+#pragma unroll
+            for (int i = 1 + p; i <= SIL_TROWS - 2 - p; i++)
+                c[i] = n[i];
+        }
+#pragma unroll
+        for (int i = SIL_HALO; i < SIL_HALO + SIL_TR; i++) {
+            if (i <= ihi) {
+                dst[(int64_t)(r0 - SIL_HALO + i) * A.W + x] = (uint8_t)c[i];
+                atomicAdd(&hist[c[i]], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t h = hist[threadIdx.x];
+    if (h)
+        atomicAdd(&A.hist[b * 256 + threadIdx.x], h);
+}
+
+// ------------------------------------------------------------ mask kernel
+// 3x3 dilation or erosion of a bit mask, scipy.ndimage semantics with
+// border_value = 0: whatever lies outside the rows x cols rectangle is
+// background for both operations.  Bits at or beyond `cols` stay zero.
+template <bool DILATE>
+__device__ void sil_morph(const uint32_t *s, uint32_t *d, int rows, int cols, int wpr)
+{
+    const int wc = (cols + 31) >> 5;
+    const uint32_t lastmask = (cols & 31) ? ((1u << (cols & 31)) - 1u) : ~0u;
+    for (int wi = threadIdx.x; wi < rows * wc; wi += FX_BLOCK) {
+        const int y = wi / wc, w = wi - y * wc;
+        uint32_t acc = DILATE ? 0u : ~0u;
+#pragma unroll
+        for (int dy = -1; dy <= 1; dy++) {
+            const int yy = y + dy;
+            uint32_t h = 0u;
+            if (yy >= 0 && yy < rows) {
+                const uint32_t *r = s + yy * wpr;
+                const uint32_t m = r[w];
+                const uint32_t p = w > 0 ? r[w - 1] : 0u;
+                const uint32_t n = w + 1 < wc ? r[w + 1] : 0u;
+                const uint32_t L = (m << 1) | (p >> 31), R = (m >> 1) | (n << 31);
+                h = DILATE ? (m | L | R) : (m & L & R);
+            }
+            acc = DILATE ? (acc | h) : (acc & h);
+        }
+        if (w == wc - 1)
+            acc &= lastmask;
+        d[y * wpr + w] = acc;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ uint32_t sil_find(volatile uint32_t *parent, uint32_t a)
+{
+    uint32_t p;
+    while ((p = parent[a]) != a)
+        a = p;
+    return a;
+}
+
+// Lock-free union, the smaller index becomes the root.
+__device__ void sil_unite(uint32_t *parent, uint32_t a, uint32_t b)
+{
+    for (;;) {
+        a = sil_find(parent, a);
+        b = sil_find(parent, b);
+        if (a == b)
+            return;
+        if (a < b) {
+            const uint32_t t = a;
+            a = b;
+            b = t;
+        }
+        const uint32_t old = atomicMin(&parent[a], b);
+        if (old == a)
+            return;
+        a = old;  // somebody linked `a` first; join that tree with b as well
+    }
+}
+
+// bits of m up to and including position `bit`
+__device__ __forceinline__ uint32_t sil_le(int bit) { return bit >= 31 ? ~0u : ((2u << bit) - 1u); }
+
+enum {
+    SV_COUNT = 0, SV_THRESH, SV_INV, SV_MINX, SV_MINY, SV_MAXX, SV_MAXY, SV_CX0, SV_CY0, SV_CW, SV_CH, SV_NW,
+    SV_NH, SV_NRUNS, SV_ANYKEEP, SV_N
+};
+
+__global__ __launch_bounds__(FX_BLOCK) void sil_mask_kernel(SilArgs A)
+{
+    extern __shared__ __align__(16) uint8_t sil_smem[];
+    __shared__ double s_between[256];
+    __shared__ uint32_t s_hist[256];
+    __shared__ uint32_t s_scan[256];
+    __shared__ uint16_t s_xtab[SIL_MAX_SIDE], s_ytab[SIL_MAX_SIDE];
+    __shared__ uint32_t s_parent[SIL_RUNS_LDS], s_size[SIL_RUNS_LDS];
+    __shared__ int s_v[SV_N];
+    __shared__ unsigned long long s_best;
+
+    const int t = threadIdx.x;
+    const int nw = A.rows * A.wpr;
+    uint32_t *mA = (uint32_t *)sil_smem;
+    uint32_t *mB = mA + nw;
+    uint32_t *pre = mB + nw;
+    const int H = A.H, W = A.W, wpr = A.wpr, res = A.res;
+    const int wcH = (W + 31) >> 5;
+    const uint32_t lastH = (W & 31) ? ((1u << (W & 31)) - 1u) : ~0u;
+
+    for (int64_t b = blockIdx.x; b < A.B; b += gridDim.x) {
+        __syncthreads();
+        // ---- Otsu level (reference :101-126): float64 in the reference's order
+        s_hist[t] = A.hist[b * 256 + t];
+        if (t < SV_N)
+            s_v[t] = t == SV_MINX ? W : t == SV_MINY ? H : (t == SV_MAXX || t == SV_MAXY) ? -1 : 0;
+        if (t == 0)
+            s_best = 0ull;
+        __syncthreads();
+        {
+            u64 wb = 0, sb = 0, wt = 0;
+            for (int k = 0; k < 256; k++) {
+                const u64 h = s_hist[k];
+                wt += (u64)k * h;
+                if (k <= t) {
+                    wb += h;
+                    sb += (u64)k * h;
+                }
+            }
+            const u64 total = (u64)H * (u64)W;
+            double between = -1.0;  // level not considered
+            if (wb > 0 && total - wb > 0) {
+                const double w_back = (double)wb, w_fore = (double)(total - wb);
+                const double m_back = (double)sb / w_back;
+                const double m_fore = (double)(wt - sb) / w_fore;
+                const double d = m_back - m_fore;
+                between = ((w_back * w_fore) * d) * d;
+            }
+            s_between[t] = between;
+        }
+        __syncthreads();
+        if (t == 0) {
+            double best = 0.0;
+            int level = 0;
+            for (int i = 0; i < 256; i++) {
+                const double bt = s_between[i];
+                if (bt >= 0.0 && bt >= best) {  // ties go to the higher level
+                    best = bt;
+                    level = i;
+                }
+            }
+            s_v[SV_THRESH] = level;
+        }
+        __syncthreads();
+        const uint32_t thresh = (uint32_t)s_v[SV_THRESH];
+
+        // ---- bit mask of blur > thresh
+        const uint8_t *blur = A.blur + b * (int64_t)H * W;
+        {
+            uint32_t cnt = 0;
+            for (int wi = t; wi < H * wcH; wi += FX_BLOCK) {
+                const int y = wi / wcH, w = wi - y * wcH;
+                const uint8_t *p = blur + (int64_t)y * W + 32 * w;
+                uint32_t word = 0;
+                if ((W & 15) == 0) {
+                    const int nq = 32 * w + 16 < W ? 2 : 1;
+                    for (int q = 0; q < nq; q++) {
+                        const uint4 m = *(const uint4 *)(p + 16 * q);
+                        const uint32_t mw[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+                        for (int k = 0; k < 16; k++)
+                            word |= (((mw[k >> 2] >> (8 * (k & 3))) & 255u) > thresh ? 1u : 0u) << (16 * q + k);
+                    }
+                } else {
+                    for (int k = 0; k < 32 && 32 * w + k < W; k++)
+                        word |= (p[k] > thresh ? 1u : 0u) << k;
+                }
+                mA[y * wpr + w] = word;
+                cnt += __popc(word);
+            }
+            if (cnt)
+                atomicAdd(&s_v[SV_COUNT], (int)cnt);
+        }
+        __syncthreads();
+        // foreground above half of the image: the silhouette is the other class
+        const bool inverted = 2ll * s_v[SV_COUNT] > (long long)H * W;
+        if (inverted) {
+            for (int wi = t; wi < H * wcH; wi += FX_BLOCK) {
+                const int y = wi / wcH, w = wi - y * wcH;
+                uint32_t word = ~mA[y * wpr + w];
+                if (w == wcH - 1)
+                    word &= lastH;
+                mA[y * wpr + w] = word;
+            }
+        }
+        __syncthreads();
+
+        // ---- 3x3 closing then opening (reference :170-186)
+        sil_morph<true>(mA, mB, H, W, wpr);
+        sil_morph<false>(mB, mA, H, W, wpr);
+        sil_morph<false>(mA, mB, H, W, wpr);
+        sil_morph<true>(mB, mA, H, W, wpr);
+
+        // ---- bounding box of the foreground (reference :191-221, branch without cv2)
+        {
+            int mnx = W, mny = H, mxx = -1, mxy = -1;
+            for (int wi = t; wi < H * wcH; wi += FX_BLOCK) {
+                const int y = wi / wcH, w = wi - y * wcH;
+                const uint32_t m = mA[y * wpr + w];
+                if (m) {
+                    const int lo = 32 * w + __ffs((int)m) - 1, hi = 32 * w + 31 - __clz((int)m);
+                    mnx = lo < mnx ? lo : mnx;
+                    mxx = hi > mxx ? hi : mxx;
+                    mny = y < mny ? y : mny;
+                    mxy = y > mxy ? y : mxy;
+                }
+            }
+            if (mxx >= 0) {
+                atomicMin(&s_v[SV_MINX], mnx);
+                atomicMin(&s_v[SV_MINY], mny);
+                atomicMax(&s_v[SV_MAXX], mxx);
+                atomicMax(&s_v[SV_MAXY], mxy);
+            }
+        }
+        __syncthreads();
+
+        // ---- crop rectangle and target size (reference :352-440)
+        if (t == 0) {
+            int x0 = 0, y0 = 0, x1 = W, y1 = H;
+            if (A.crop) {
+                int bx = 0, by = 0, bw = W, bh = H;
+                if (s_v[SV_MAXX] >= 0) {
+                    bx = s_v[SV_MINX];
+                    by = s_v[SV_MINY];
+                    bw = s_v[SV_MAXX] - bx + 1;
+                    bh = s_v[SV_MAXY] - by + 1;
+                }
+                const int side = bw > bh ? bw : bh;
+                // Python round(): half to even
+                const int pad = A.crop_margin <= 1.0 ? (int)rint(A.crop_margin * (double)side)
+                                                     : (int)rint(A.crop_margin);
+                x0 = bx - pad > 0 ? bx - pad : 0;
+                y0 = by - pad > 0 ? by - pad : 0;
+                x1 = bx + bw + pad < W ? bx + bw + pad : W;
+                y1 = by + bh + pad < H ? by + bh + pad : H;
+                if (x1 <= x0 || y1 <= y0) {
+                    x0 = 0;
+                    y0 = 0;
+                    x1 = W;
+                    y1 = H;
+                }
+            }
+            const int cw = x1 - x0, ch = y1 - y0;
+            const double sx = (double)res / (double)cw, sy = (double)res / (double)ch;
+            const double scale = sx < sy ? sx : sy;
+            int new_w = (int)rint((double)cw * scale), new_h = (int)rint((double)ch * scale);
+            new_w = new_w < 1 ? 1 : (new_w > res ? res : new_w);
+            new_h = new_h < 1 ? 1 : (new_h > res ? res : new_h);
+            s_v[SV_CX0] = x0;
+            s_v[SV_CY0] = y0;
+            s_v[SV_CW] = cw;
+            s_v[SV_CH] = ch;
+            s_v[SV_NW] = new_w;
+            s_v[SV_NH] = new_h;
+        }
+        __syncthreads();
+        const int cx0 = s_v[SV_CX0], cy0 = s_v[SV_CY0], cw = s_v[SV_CW], ch = s_v[SV_CH];
+        const int new_w = s_v[SV_NW], new_h = s_v[SV_NH];
+        // PIL's nearest resize steps through the source with a float64
+        // accumulator: xo = a/2, then xo += a per output pixel.
+        if (t == 0 || t == FX_WAVE) {
+            const int n_out = t == 0 ? new_w : new_h, n_in = t == 0 ? cw : ch;
+            uint16_t *tab = t == 0 ? s_xtab : s_ytab;
+            const double a = (double)n_in / (double)n_out;
+            double xo = a * 0.5;
+            for (int x = 0; x < n_out; x++) {
+                const int xin = (int)xo;
+                tab[x] = xin < n_in ? (uint16_t)xin : (uint16_t)0xFFFF;
+                xo += a;
+            }
+        }
+        __syncthreads();
+
+        // ---- resized mask (new_h x new_w) into mB
+        const int wcS = (new_w + 31) >> 5;
+        for (int wi = t; wi < new_h * wcS; wi += FX_BLOCK) {
+            const int y = wi / wcS, w = wi - y * wcS;
+            const uint32_t sy = s_ytab[y];
+            uint32_t word = 0;
+            if (sy != 0xFFFFu) {
+                const uint32_t *r = mA + (cy0 + (int)sy) * wpr;
+                for (int k = 0; k < 32 && 32 * w + k < new_w; k++) {
+                    const uint32_t sx = s_xtab[32 * w + k];
+                    if (sx != 0xFFFFu) {
+                        const int x = cx0 + (int)sx;
+                        word |= ((r[x >> 5] >> (x & 31)) & 1u) << k;
+                    }
+                }
+            }
+            mB[y * wpr + w] = word;
+        }
+        __syncthreads();
+
+        // ---- 3x3 opening of the resized mask (reference :246-346)
+        sil_morph<false>(mB, mA, new_h, new_w, wpr);
+        sil_morph<true>(mA, mB, new_h, new_w, wpr);
+
+        // ---- 4-connected components over row runs
+        // A run is named by the raster-order rank of its first pixel: the run
+        // that holds a set pixel is the latest run started at or before it.
+        const int nwS = new_h * wcS;
+        const int per = (nwS + FX_BLOCK - 1) / FX_BLOCK;
+        {
+            uint32_t local = 0;
+            for (int j = 0; j < per; j++) {
+                const int wi = t * per + j;
+                if (wi < nwS) {
+                    const int y = wi / wcS, w = wi - y * wcS;
+                    const uint32_t m = mB[y * wpr + w];
+                    const uint32_t p = w > 0 ? mB[y * wpr + w - 1] : 0u;
+                    local += __popc(m & ~((m << 1) | (p >> 31)));
+                }
+            }
+            s_scan[t] = local;
+        }
+        __syncthreads();
+        {
+            uint32_t base = 0, total = 0;
+            for (int k = 0; k < FX_BLOCK; k++) {
+                const uint32_t v = s_scan[k];
+                base += k < t ? v : 0u;
+                total += v;
+            }
+            for (int j = 0; j < per; j++) {
+                const int wi = t * per + j;
+                if (wi < nwS) {
+                    const int y = wi / wcS, w = wi - y * wcS;
+                    const uint32_t m = mB[y * wpr + w];
+                    const uint32_t p = w > 0 ? mB[y * wpr + w - 1] : 0u;
+                    pre[wi] = base;
+                    base += __popc(m & ~((m << 1) | (p >> 31)));
+                }
+            }
+            if (t == 0)
+                s_v[SV_NRUNS] = (int)total;
+        }
+        __syncthreads();
+        const int nruns = s_v[SV_NRUNS];
+        uint32_t *parent = nruns <= SIL_RUNS_LDS ? s_parent : A.runs + (int64_t)blockIdx.x * 2 * A.run_cap;
+        uint32_t *rsize = nruns <= SIL_RUNS_LDS ? s_size : parent + A.run_cap;
+        for (int r = t; r < nruns; r += FX_BLOCK) {
+            parent[r] = (uint32_t)r;
+            rsize[r] = 0u;
+        }
+        __syncthreads();
+        // runs of neighbouring rows that share a column belong together
+        for (int wi = t + wcS; wi < nwS; wi += FX_BLOCK) {
+            const int y = wi / wcS, w = wi - y * wcS;
+            const uint32_t m = mB[y * wpr + w], u = mB[(y - 1) * wpr + w];
+            const uint32_t mp = w > 0 ? mB[y * wpr + w - 1] : 0u, up = w > 0 ? mB[(y - 1) * wpr + w - 1] : 0u;
+            const uint32_t o = m & u, op = mp & up;
+            uint32_t os = o & ~((o << 1) | (op >> 31));  // first pixel of every stretch of overlap
+            if (!os)
+                continue;
+            const uint32_t sm = m & ~((m << 1) | (mp >> 31)), su = u & ~((u << 1) | (up >> 31));
+            const uint32_t pm = pre[wi], pu = pre[wi - wcS];
+            while (os) {
+                const int bit = __ffs((int)os) - 1;
+                os &= os - 1;
+                const uint32_t le = sil_le(bit);
+                sil_unite(parent, pm + __popc(sm & le) - 1u, pu + __popc(su & le) - 1u);
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        for (int r = t; r < nruns; r += FX_BLOCK)
+            parent[r] = sil_find(parent, (uint32_t)r);
+        __threadfence_block();
+        __syncthreads();
+        // component sizes
+        for (int wi = t; wi < nwS; wi += FX_BLOCK) {
+            const int y = wi / wcS, w = wi - y * wcS;
+            uint32_t m = mB[y * wpr + w];
+            if (!m)
+                continue;
+            const uint32_t mp = w > 0 ? mB[y * wpr + w - 1] : 0u;
+            const uint32_t sm = m & ~((m << 1) | (mp >> 31));
+            const uint32_t pm = pre[wi];
+            while (m) {
+                const uint32_t low = m & (0u - m);
+                const uint32_t seg = m & ~(m + low);  // the lowest stretch of ones
+                const int bit = __ffs((int)m) - 1;
+                const uint32_t id = pm + __popc(sm & sil_le(bit)) - 1u;
+                atomicAdd(&rsize[parent[id]], (uint32_t)__popc(seg));
+                m &= ~seg;
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        // keep components of at least min_size pixels; when none is that large
+        // keep the largest one, the first in raster order among equals
+        for (int r = t; r < nruns; r += FX_BLOCK) {
+            if (parent[r] == (uint32_t)r) {
+                const uint32_t sz = rsize[r];
+                if ((int)sz >= A.min_size)
+                    s_v[SV_ANYKEEP] = 1;
+                atomicMax(&s_best, ((unsigned long long)sz << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)r));
+            }
+        }
+        __syncthreads();
+        const bool any_keep = s_v[SV_ANYKEEP] != 0;
+        const uint32_t best_root = 0xFFFFFFFFu - (uint32_t)(s_best & 0xFFFFFFFFull);
+        // kept pixels into mA
+        for (int wi = t; wi < nwS; wi += FX_BLOCK) {
+            const int y = wi / wcS, w = wi - y * wcS;
+            uint32_t m = mB[y * wpr + w], kept = 0u;
+            if (m) {
+                const uint32_t mp = w > 0 ? mB[y * wpr + w - 1] : 0u;
+                const uint32_t sm = m & ~((m << 1) | (mp >> 31));
+                const uint32_t pm = pre[wi];
+                while (m) {
+                    const uint32_t low = m & (0u - m);
+                    const uint32_t seg = m & ~(m + low);
+                    const int bit = __ffs((int)m) - 1;
+                    const uint32_t root = parent[pm + __popc(sm & sil_le(bit)) - 1u];
+                    const bool keep = any_keep ? (int)rsize[root] >= A.min_size : root == best_root;
+                    kept |= keep ? seg : 0u;
+                    m &= ~seg;
+                }
+            }
+            mA[y * wpr + w] = kept;
+        }
+        __syncthreads();
+
+        // ---- centred paste on the res x res canvas
+        const int px0 = (res - new_w) / 2, py0 = (res - new_h) / 2;
+        uint8_t *out = A.mask + b * (int64_t)res * res;
+        if ((res & 15) == 0) {
+            const int cpr = res >> 4;
+            for (int ci = t; ci < res * cpr; ci += FX_BLOCK) {
+                const int Y = ci / cpr, X0 = (ci - Y * cpr) * 16;
+                const int y = Y - py0;
+                uint32_t o[4] = {0u, 0u, 0u, 0u};
+                if (y >= 0 && y < new_h) {
+                    const uint32_t *r = mA + y * wpr;
+#pragma unroll
+                    for (int k = 0; k < 16; k++) {
+                        const int x = X0 + k - px0;
+                        if (x >= 0 && x < new_w && ((r[x >> 5] >> (x & 31)) & 1u))
+                            o[k >> 2] |= 255u << (8 * (k & 3));
+                    }
+                }
+                *(uint4 *)(out + (int64_t)Y * res + X0) = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+        } else {
+            for (int pi = t; pi < res * res; pi += FX_BLOCK) {
+                const int Y = pi / res, X = pi - Y * res;
+                const int y = Y - py0, x = X - px0;
+                uint8_t v = 0;
+                if (y >= 0 && y < new_h && x >= 0 && x < new_w && ((mA[y * wpr + (x >> 5)] >> (x & 31)) & 1u))
+                    v = 255;
+                out[pi] = v;
+            }
+        }
+        if (A.info && t == 0) {
+            int32_t *f = A.info + b * 8;
+            f[0] = (int32_t)thresh;
+            f[1] = inverted ? 1 : 0;
+            f[2] = cx0;
+            f[3] = cy0;
+            f[4] = cx0 + cw;
+            f[5] = cy0 + ch;
+            f[6] = new_w;
+            f[7] = new_h;
+        }
+    }
+}
+
+inline size_t sil_align(size_t v) { return (v + 255) & ~(size_t)255; }
+
+}  // namespace
+
+extern "C" int fx_silhouette_batch_u8(const uint8_t *d_img, int64_t B, int H, int W, int64_t pitch, int64_t stride,
+                                      int resolution, double crop_margin, int preprocess_crop, int min_size,
+                                      uint8_t *d_mask, int32_t *d_info, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    FX_REQUIRE(B >= 0, "fx_silhouette_batch_u8: B = %lld", (long long)B);
+    if (B == 0)
+        return FX_OK;
+    FX_REQUIRE(d_img && d_mask, "fx_silhouette_batch_u8: null image or mask pointer");
+    FX_REQUIRE(H >= 1 && W >= 1 && H <= SIL_MAX_SIDE && W <= SIL_MAX_SIDE,
+               "fx_silhouette_batch_u8: views of %dx%d; supported up to %dx%d", H, W, SIL_MAX_SIDE, SIL_MAX_SIDE);
+    FX_REQUIRE(resolution >= 1 && resolution <= SIL_MAX_SIDE, "fx_silhouette_batch_u8: resolution %d outside 1..%d",
+               resolution, SIL_MAX_SIDE);
+    FX_REQUIRE(pitch >= W && (B == 1 || stride >= (int64_t)(H - 1) * pitch + W),
+               "fx_silhouette_batch_u8: pitch %lld / stride %lld too small for %dx%d", (long long)pitch,
+               (long long)stride, H, W);
+    FX_REQUIRE(crop_margin >= 0.0 && crop_margin < 1e9, "fx_silhouette_batch_u8: crop_margin %g", crop_margin);
+    if (min_size < 0) {
+        // int(0.001 * resolution * resolution), at least 8 (reference :262-263)
+        const double v = 0.001 * (double)resolution * (double)resolution;
+        min_size = (int)v > 8 ? (int)v : 8;
+    }
+
+    const int64_t px = (int64_t)H * W;
+    int64_t chunk = (int64_t)(1ll << 30) / px;
+    chunk = chunk < 1 ? 1 : (chunk > 32768 ? 32768 : chunk);
+    chunk = chunk > B ? B : chunk;
+    const int grid = (int)(chunk < SIL_MAX_GRID ? chunk : SIL_MAX_GRID);
+    const int rows = H > resolution ? H : resolution;
+    const int side = W > resolution ? W : resolution;
+    const int wpr = (side + 31) / 32;
+    const int run_cap = resolution * (resolution / 2 + 1);
+
+    const size_t blur_bytes = sil_align((size_t)chunk * px);
+    const size_t hist_bytes = sil_align((size_t)chunk * 256 * sizeof(uint32_t));
+    const size_t runs_bytes = sil_align((size_t)grid * 2 * run_cap * sizeof(uint32_t));
+    unsigned char *base = (unsigned char *)fx_scratch(blur_bytes + hist_bytes + runs_bytes, 3);
+    if (!base)
+        return FX_ENOMEM;
+
+    SilArgs A;
+    A.H = H;
+    A.W = W;
+    A.pitch = pitch;
+    A.stride = stride;
+    A.res = resolution;
+    A.crop_margin = crop_margin;
+    A.crop = preprocess_crop ? 1 : 0;
+    A.min_size = min_size;
+    A.blur = base;
+    A.hist = (uint32_t *)(base + blur_bytes);
+    A.runs = (uint32_t *)(base + blur_bytes + hist_bytes);
+    A.run_cap = run_cap;
+    A.wpr = wpr;
+    A.rows = rows;
+
+    const bool aligned = (W % 16 == 0) && (pitch % 16 == 0) && (stride % 16 == 0) && (((uintptr_t)d_img) % 16 == 0);
+    const int Wp = (W + 15) & ~15;
+    const size_t blur_lds = (size_t)SIL_TROWS * Wp + 256 * sizeof(uint32_t);
+    const size_t mask_lds = (size_t)3 * rows * wpr * sizeof(uint32_t);
+    static bool attr_set = false;
+    if (!attr_set) {
+        FX_HIP_CHECK(hipFuncSetAttribute((const void *)sil_mask_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         3 * SIL_MAX_SIDE * (SIL_MAX_SIDE / 32) * (int)sizeof(uint32_t)));
+        attr_set = true;
+    }
+
+    FxProfileScope prof(stream);
+    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+        const int64_t nb = B - b0 < chunk ? B - b0 : chunk;
+        A.img = d_img + b0 * stride;
+        A.B = nb;
+        A.mask = d_mask + b0 * (int64_t)resolution * resolution;
+        A.info = d_info ? d_info + b0 * 8 : nullptr;
+        FX_HIP_CHECK(hipMemsetAsync(A.hist, 0, (size_t)nb * 256 * sizeof(uint32_t), stream));
+        const dim3 bgrid((unsigned)((H + SIL_TR - 1) / SIL_TR), (unsigned)nb);
+        if (aligned)
+            hipLaunchKernelGGL(sil_blur_kernel<true>, bgrid, dim3(FX_BLOCK), blur_lds, stream, A);
+        else
+            hipLaunchKernelGGL(sil_blur_kernel<false>, bgrid, dim3(FX_BLOCK), blur_lds, stream, A);
+        FX_HIP_CHECK(hipGetLastError());
+        const int g = (int)(nb < grid ? nb : grid);
+        hipLaunchKernelGGL(sil_mask_kernel, dim3(g), dim3(FX_BLOCK), mask_lds, stream, A);
+        FX_HIP_CHECK(hipGetLastError());
+    }
+    return FX_OK;
+}

@@ -76,6 +76,32 @@ def hu_batch(images: torch.Tensor, thresh: int = -1, on_value: int = 255, *, mom
     return out
 
 
+def silhouette_batch(images: torch.Tensor, resolution: int = 224, crop_margin: float = 0.05,
+                     preprocess_crop: bool = True, min_size: int = -1, *, info: bool = False) -> dict:
+    """Cleaned 0/255 silhouettes [B, resolution, resolution] of a batch of gray
+    uint8 views [B, H, W] (Gaussian blur, Otsu, morphology, crop, nearest
+    resize, component filter).  With info=True also "info" int32 [B, 8]:
+    Otsu level, inverted flag, crop x0 y0 x1 y1, resized width and height."""
+    _require_cuda(images, "images")
+    if images.dtype != torch.uint8 or images.dim() != 3:
+        raise ValueError(f"images must be uint8 [B, H, W], got {images.dtype} {tuple(images.shape)}")
+    if images.stride(2) != 1 and images.shape[2] > 1:
+        raise ValueError("images must have a unit stride along the row")
+    stream = _enter(images.device)
+    B, H, W = images.shape
+    res = int(resolution)
+    out = {"mask": torch.empty((B, res, res), dtype=torch.uint8, device=images.device)}
+    if info:
+        out["info"] = torch.empty((B, 8), dtype=torch.int32, device=images.device)
+    if B == 0:
+        return out
+    pitch = images.stride(1) if H > 1 else W
+    stride = images.stride(0) if B > 1 else pitch * H
+    _lib.call("fx_silhouette_batch_u8", images.data_ptr(), B, H, W, pitch, stride, res, float(crop_margin),
+              int(bool(preprocess_crop)), int(min_size), out["mask"].data_ptr(), _ptr(out.get("info")), stream)
+    return out
+
+
 def hu_groupstat(hulog7: torch.Tensor, group_offsets: torch.Tensor) -> torch.Tensor:
     """mean || std (ddof=0, float32) of the rows of each group -> f32 [G, 14]."""
     _require_cuda(hulog7, "hulog7")

@@ -6,11 +6,13 @@ compute_hu_from_image (:443-478: cv2.moments, cv2.HuMoments, log transform) and
 of the per-sample mean/std (:641-644) runs in the HIP kernels of libfx
 (csrc/fx_hu.hip); there is no CPU fallback for it.
 
-Image decoding and the silhouette preprocessing (Otsu, crop, resize, mask
-cleaning, :84-440) stay on the host here and follow the code path the
-reference itself takes when OpenCV is not installed (PIL + scipy.ndimage),
-which is the only one of its two paths that can be run and checked in an
-environment without cv2.
+The silhouette preprocessing in front of it (:101-440: blur, Otsu, morphology,
+bounding-box crop, nearest resize, mask cleaning) runs on the device as well
+(csrc/fx_sil.hip) and follows the code path the reference itself takes when
+OpenCV is not installed (PIL + scipy.ndimage), which is the only one of its two
+paths that can be run and checked in an environment without cv2.  Image
+decoding, and the bicubic fit of the gray image that is only needed without
+--use_silhouette, are PIL calls on the host.
 
 Added next to the reference API: `compute_hu_batch` and `process_samples`,
 which push many views through one kernel launch.
@@ -25,14 +27,7 @@ from pathlib import Path
 from typing import Any, Dict, Iterable, List, Optional, Sequence, Tuple
 
 import numpy as np
-from PIL import Image, ImageFilter, ImageOps
-
-try:
-    from scipy import ndimage as ndi
-    _HAS_NDIMAGE = True
-except Exception:  # pragma: no cover
-    ndi = None
-    _HAS_NDIMAGE = False
+from PIL import Image, ImageOps
 
 logger = logging.getLogger("extract_2d_hu")
 
@@ -65,134 +60,6 @@ def load_image(path: Path) -> np.ndarray:
 
 
 # --------------------------------------------------------------------------
-# host-side silhouette preprocessing (reference :101-440, no-OpenCV branch)
-# --------------------------------------------------------------------------
-def _otsu_threshold_numpy(img: np.ndarray) -> int:
-    """Otsu level in [0, 255]; ties resolved towards the higher level
-    (reference :101-126 uses `>=`)."""
-    hist, _ = np.histogram(img.ravel(), bins=256, range=(0, 256))
-    total = img.size
-    weighted_total = np.dot(np.arange(256), hist)
-    w_back = 0.0
-    sum_back = 0.0
-    best, level = 0.0, 0
-    for i in range(256):
-        w_back += hist[i]
-        if w_back == 0:
-            continue
-        w_fore = total - w_back
-        if w_fore == 0:
-            break
-        sum_back += i * hist[i]
-        m_back = sum_back / w_back
-        m_fore = (weighted_total - sum_back) / w_fore
-        between = w_back * w_fore * (m_back - m_fore) * (m_back - m_fore)
-        if between >= best:
-            level, best = i, between
-    return int(level)
-
-
-def compute_otsu(img: np.ndarray) -> Tuple[int, np.ndarray]:
-    """(threshold, 0/255 mask): radius-1 Gaussian blur, Otsu, inversion when the
-    foreground exceeds half of the image, 3x3 closing then opening (reference
-    :129-188, branch without cv2)."""
-    try:
-        blur = np.asarray(Image.fromarray(img).filter(ImageFilter.GaussianBlur(radius=1)))
-    except Exception:
-        blur = img
-    thresh = _otsu_threshold_numpy(blur)
-    mask = (blur > thresh).astype(np.uint8) * 255
-    mask = (mask > 127).astype(np.uint8) * 255
-    if float(np.count_nonzero(mask) / mask.size) > 0.5:
-        mask = (255 - mask).astype(np.uint8)
-    if _HAS_NDIMAGE:
-        try:
-            b = mask > 127
-            b = ndi.binary_closing(b, structure=np.ones((3, 3)))
-            b = ndi.binary_opening(b, structure=np.ones((3, 3)))
-            mask = b.astype(np.uint8) * 255
-        except Exception:
-            pass
-    return int(thresh), mask.astype(np.uint8)
-
-
-def find_largest_bbox(mask: np.ndarray) -> Tuple[int, int, int, int]:
-    """x, y, w, h of the non-zero pixels; the whole image when there are none
-    (reference :191-221, branch without cv2)."""
-    h, w = mask.shape[:2]
-    coords = np.argwhere(mask > 0)
-    if coords.size == 0:
-        return 0, 0, w, h
-    y0, x0 = coords.min(axis=0)
-    y1, x1 = coords.max(axis=0)
-    return int(x0), int(y0), int(x1 - x0 + 1), int(y1 - y0 + 1)
-
-
-def pad_and_resize(img: np.ndarray, target: int, bg_color: str) -> np.ndarray:
-    """Aspect-preserving fit into target x target, centred on the background colour (reference :224-240)."""
-    fitted = ImageOps.contain(Image.fromarray(img), (target, target)).convert("L")
-    canvas = Image.new("L", (target, target), color=255 if bg_color == "white" else 0)
-    canvas.paste(fitted, ((target - fitted.width) // 2, (target - fitted.height) // 2))
-    return np.asarray(canvas, dtype=np.uint8)
-
-
-def clean_mask_np(mask_np: np.ndarray, resolution: int, min_size: Optional[int] = None) -> np.ndarray:
-    """3x3 opening, then components smaller than min_size dropped (largest kept
-    when none reaches it); default min_size = max(8, 0.1 % of resolution^2)
-    (reference :246-346, scipy.ndimage branch)."""
-    if min_size is None:
-        min_size = max(8, int(0.001 * resolution * resolution))
-    b = (mask_np > 127).astype(np.uint8)
-    if not _HAS_NDIMAGE:
-        raise RuntimeError("scipy.ndimage is required for mask cleaning")
-    b = ndi.binary_opening(b, structure=np.ones((3, 3))).astype(np.uint8)
-    labels, count = ndi.label(b)
-    if count == 0:
-        return b.astype(np.uint8) * 255
-    sizes = np.array(ndi.sum(b, labels, range(1, count + 1)))
-    keep = sizes >= min_size
-    if not keep.any():
-        keep[np.argmax(sizes)] = True
-    kept = np.isin(labels, 1 + np.nonzero(keep)[0]).astype(np.uint8)
-    return kept * 255
-
-
-def _mask_to_canvas(mask: np.ndarray, resolution: int) -> np.ndarray:
-    pil = Image.fromarray(mask).convert("L")
-    scale = min(resolution / float(pil.width), resolution / float(pil.height))
-    new_w = max(1, int(round(pil.width * scale)))
-    new_h = max(1, int(round(pil.height * scale)))
-    small = np.asarray(pil.resize((new_w, new_h), resample=Image.NEAREST), dtype=np.uint8)
-    small = clean_mask_np((small > 128).astype(np.uint8) * 255, resolution)
-    canvas = Image.new("L", (resolution, resolution), color=0)
-    canvas.paste(Image.fromarray(small).convert("L"), ((resolution - new_w) // 2, (resolution - new_h) // 2))
-    return np.asarray(canvas, dtype=np.uint8)
-
-
-def preprocess_image(img: np.ndarray, resolution: int, crop_margin: float, bg_color: str,
-                     preprocess_crop: bool) -> Tuple[np.ndarray, np.ndarray]:
-    """(preprocessed gray image, cleaned 0/255 silhouette), both
-    resolution x resolution uint8 (reference :352-440)."""
-    assert img.ndim == 2
-    h, w = img.shape[:2]
-    try:
-        _, mask = compute_otsu(img)
-    except Exception:
-        mask = (img > int(np.median(img))).astype(np.uint8) * 255
-    if not preprocess_crop:
-        return pad_and_resize(img, resolution, bg_color), _mask_to_canvas(mask, resolution)
-    x, y, ww, hh = find_largest_bbox(mask)
-    side = max(ww, hh)
-    pad = int(round(crop_margin * side)) if crop_margin <= 1.0 else int(round(crop_margin))
-    x0, y0 = max(0, x - pad), max(0, y - pad)
-    x1, y1 = min(w, x + ww + pad), min(h, y + hh + pad)
-    if x1 <= x0 or y1 <= y0:
-        x0, y0, x1, y1 = 0, 0, w, h
-    return (pad_and_resize(img[y0:y1, x0:x1], resolution, bg_color),
-            _mask_to_canvas(mask[y0:y1, x0:x1], resolution))
-
-
-# --------------------------------------------------------------------------
 # device path
 # --------------------------------------------------------------------------
 def _device():
@@ -200,6 +67,45 @@ def _device():
     if not torch.cuda.is_available():
         raise RuntimeError("no HIP device visible: the Hu extractor runs on the GPU only")
     return torch.device("cuda", torch.cuda.current_device())
+
+
+def pad_and_resize(img: np.ndarray, target: int, bg_color: str) -> np.ndarray:
+    """Aspect-preserving fit of the gray image into target x target, centred on
+    the background colour (reference :224-240).  Host code (PIL bicubic): only
+    needed when the moments are taken from the gray image instead of the
+    silhouette."""
+    fitted = ImageOps.contain(Image.fromarray(img), (target, target)).convert("L")
+    canvas = Image.new("L", (target, target), color=255 if bg_color == "white" else 0)
+    canvas.paste(fitted, ((target - fitted.width) // 2, (target - fitted.height) // 2))
+    return np.asarray(canvas, dtype=np.uint8)
+
+
+def compute_silhouettes(images: np.ndarray, resolution: int, crop_margin: float, preprocess_crop: bool):
+    """Cleaned 0/255 silhouettes of equally sized gray views [B, H, W] in one
+    device call: (uint8 [B, res, res], int32 [B, 8] = Otsu level, inverted
+    flag, crop x0 y0 x1 y1, resized width and height).  Covers compute_otsu,
+    find_largest_bbox, the mask half of preprocess_image and clean_mask_np of
+    the reference (:129-440, branch without OpenCV)."""
+    import torch
+    from . import engine
+
+    arr = np.ascontiguousarray(images, dtype=np.uint8)
+    if arr.ndim == 2:
+        arr = arr[None]
+    out = engine.silhouette_batch(torch.from_numpy(arr).to(_device()), resolution, crop_margin, preprocess_crop,
+                                  info=True)
+    return out["mask"].cpu().numpy(), out["info"].cpu().numpy()
+
+
+def preprocess_image(img: np.ndarray, resolution: int, crop_margin: float, bg_color: str,
+                     preprocess_crop: bool) -> Tuple[np.ndarray, np.ndarray]:
+    """(preprocessed gray image, cleaned 0/255 silhouette), both
+    resolution x resolution uint8 (reference :352-440).  The silhouette and the
+    crop rectangle come from the device; the gray fit is PIL on the host."""
+    assert img.ndim == 2
+    masks, info = compute_silhouettes(img, resolution, crop_margin, preprocess_crop)
+    x0, y0, x1, y1 = (int(v) for v in info[0, 2:6])
+    return pad_and_resize(img[y0:y1, x0:x1], resolution, bg_color), masks[0]
 
 
 def compute_hu_batch(images: Sequence[np.ndarray] | np.ndarray, thresh: int = -1, on_value: int = 255,
@@ -267,17 +173,21 @@ def _log_error(reports_dir: Path, where, kind: str, msg) -> None:
 
 
 def process_samples(tasks: Iterable[Tuple[str, str, Dict[str, Any]]]) -> List[Dict[str, Any]]:
-    """Batched process_sample_worker: decodes and preprocesses every view of
-    every sample on the host, sends all targets through one moment launch and
-    one group mean/std launch, writes <id>_hu.npy per sample and returns one
-    {"success", "id", "vec", "note"} dict per task in task order (reference
-    :602-667).  Views that fail to load are logged to
-    <reports_dir>/read_errors.log and skipped; a sample without usable views
-    fails with note "failed: ..."."""
+    """Batched process_sample_worker: decodes every view of every sample on the
+    host, then per distinct (view size, settings) one silhouette call, one
+    moment launch and one group mean/std launch on the device; writes
+    <id>_hu.npy per sample and returns one {"success", "id", "vec", "note"}
+    dict per task in task order (reference :602-667).  Views that fail to load
+    are logged to <reports_dir>/read_errors.log and skipped; a sample without
+    usable views fails with note "failed: ..."."""
+    import torch
+    from . import engine
+
     tasks = list(tasks)
     results: List[Dict[str, Any]] = []
-    targets: List[np.ndarray] = []
+    views: List[np.ndarray] = []
     owners: List[int] = []
+    keys: List[tuple] = []
     for k, (sample_id, dir_path_str, config) in enumerate(tasks):
         res = {"success": False, "id": sample_id, "vec": None, "note": ""}
         results.append(res)
@@ -291,30 +201,41 @@ def process_samples(tasks: Iterable[Tuple[str, str, Dict[str, Any]]]) -> List[Di
             for vpath in view_files:
                 try:
                     img = load_image(vpath)
-                    preproc, mask = preprocess_image(img, int(config["resolution"]), float(config["crop_margin"]),
-                                                     config["bg_color"], bool(config["preprocess_crop"]))
-                    targets.append(mask if bool(config["use_silhouette"]) else preproc)
+                    views.append(img)
                     owners.append(k)
+                    keys.append((img.shape, int(config["resolution"]), float(config["crop_margin"]),
+                                 bool(config["preprocess_crop"]), bool(config["use_silhouette"]),
+                                 str(config["bg_color"])))
                 except Exception as e:
                     _log_error(reports_dir, vpath, type(e).__name__, e)
         except Exception as e:
             _log_error(reports_dir, dir_path, type(e).__name__, e)
             res["note"] = f"failed: {e}"
 
-    owners_arr = np.asarray(owners, dtype=np.int64)
     stats_by_task: Dict[int, np.ndarray] = {}
-    # one launch per distinct target shape (normally a single one: resolution^2)
-    shapes = sorted({t.shape for t in targets})
-    for shp in shapes:
-        idx = [i for i, t in enumerate(targets) if t.shape == shp]
-        own = owners_arr[idx]
-        order = np.argsort(own, kind="stable")
-        own = own[order]
-        uniq, counts = np.unique(own, return_counts=True)
-        stack = np.stack([targets[idx[i]] for i in order])
+    # one pass per distinct (view size, settings): normally a single one
+    for key in sorted(set(keys)):
+        idx = [i for i, kk in enumerate(keys) if kk == key]      # task order, so owners ascend
+        _, resolution, crop_margin, preprocess_crop, use_silhouette, bg_color = key
+        uniq, counts = np.unique(np.asarray([owners[i] for i in idx], dtype=np.int64), return_counts=True)
         try:
-            _, stats = compute_hu_batch(stack, group_sizes=counts.tolist())
+            dev = _device()
+            raw = torch.from_numpy(np.stack([views[i] for i in idx])).to(dev)
+            sil = engine.silhouette_batch(raw, resolution, crop_margin, preprocess_crop, info=not use_silhouette)
+            if use_silhouette:
+                target = sil["mask"]
+            else:
+                info = sil["info"].cpu().numpy()
+                target = torch.from_numpy(np.stack([
+                    pad_and_resize(views[i][r[3]:r[5], r[2]:r[4]], resolution, bg_color)
+                    for i, r in zip(idx, info)])).to(dev)
+            off = np.zeros(len(counts) + 1, dtype=np.int64)
+            np.cumsum(counts, out=off[1:])
+            rows = engine.hu_batch(target)["hulog7"]
+            stats = engine.hu_groupstat(rows, torch.from_numpy(off).to(dev)).cpu().numpy()
             for g, k in enumerate(uniq.tolist()):
+                if k in stats_by_task:      # views of one sample in two sizes: not a valid sample
+                    results[k]["note"] = "failed: views of different sizes"
                 stats_by_task[k] = stats[g]
         except Exception as e:
             for k in uniq.tolist():

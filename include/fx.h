@@ -124,6 +124,34 @@ int fx_pca_batch_f32(const float *d_pts, const int64_t *d_offsets, int64_t B,
                      float *d_out, double *d_eig, void *stream);
 
 /*
+ * Silhouette preprocessing of B gray views H x W (both <= 512), the step the
+ * reference runs in front of the Hu moments, on the branch it takes when
+ * OpenCV is not installed.  Replaces, per view,
+ *   compute_otsu        src/features/extract_2d_hu.py:129-188  (PIL
+ *                       GaussianBlur(radius=1), Otsu level :101-126, inversion
+ *                       when the foreground exceeds half of the view,
+ *                       scipy.ndimage 3x3 closing then opening)
+ *   find_largest_bbox   :191-221  (bounding box of the non-zero pixels)
+ *   preprocess_image    :352-440  (crop by the box + crop_margin, or the whole
+ *                       view when preprocess_crop == 0; PIL nearest resize to
+ *                       fit resolution x resolution; centred paste)
+ *   clean_mask_np       :246-346  (3x3 opening, 4-connected components below
+ *                       min_size pixels dropped, the largest kept when none
+ *                       reaches it; min_size < 0 selects the reference default
+ *                       max(8, int(0.001 * resolution^2)))
+ * and writes the cleaned 0/255 silhouette d_mask [B, resolution, resolution],
+ * bit-identical to the reference's second return value of preprocess_image.
+ * crop_margin <= 1 is a fraction of the longer box side, > 1 is in pixels.
+ * d_info (optional) int32 [B, 8]: Otsu level, 1 if the mask was inverted, crop
+ * rectangle x0, y0, x1, y1 (exclusive ends), resized width and height.
+ * The gray output of preprocess_image (PIL bicubic fit) is not produced here.
+ */
+int fx_silhouette_batch_u8(const uint8_t *d_img, int64_t B, int H, int W,
+                           int64_t pitch, int64_t stride, int resolution,
+                           double crop_margin, int preprocess_crop, int min_size,
+                           uint8_t *d_mask, int32_t *d_info, void *stream);
+
+/*
  * Synthetic inputs for benchmarks and parity tests (no reference counterpart:
  * the reference reads rendered PNG views and sampled .npy clouds from disk).
  * Image `first_index + b` / set `first_index + b` depends only on (seed, that

@@ -264,6 +264,156 @@ def contour_pca_features(img: np.ndarray, thresh: int = 127, n_bins: int = 8,
 # --------------------------------------------------------------------------
 # C oracle binding
 # --------------------------------------------------------------------------
+# --------------------------------------------------------------------------
+# Silhouette preprocessing: the reference's branch without OpenCV
+# (src/features/extract_2d_hu.py:101-440), restated with the same PIL and
+# scipy.ndimage calls.  Pinned by tests/golden/preprocess_golden.npz, which
+# holds the reference's own outputs.
+# --------------------------------------------------------------------------
+def otsu_threshold(img: np.ndarray) -> int:
+    """Otsu level in [0, 255]; ties resolved towards the higher level
+    (reference :101-126 uses `>=`)."""
+    hist, _ = np.histogram(img.ravel(), bins=256, range=(0, 256))
+    total = img.size
+    weighted_total = np.dot(np.arange(256), hist)
+    w_back = 0.0
+    sum_back = 0.0
+    best, level = 0.0, 0
+    for i in range(256):
+        w_back += hist[i]
+        if w_back == 0:
+            continue
+        w_fore = total - w_back
+        if w_fore == 0:
+            break
+        sum_back += i * hist[i]
+        m_back = sum_back / w_back
+        m_fore = (weighted_total - sum_back) / w_fore
+        between = w_back * w_fore * (m_back - m_fore) * (m_back - m_fore)
+        if between >= best:
+            level, best = i, between
+    return int(level)
+
+
+def pil_gaussian_blur_r1(img: np.ndarray) -> np.ndarray:
+    """What PIL's GaussianBlur(radius=1) computes on an 8-bit image, written
+    out: three box passes of radius 0.25 along x, then three along y, each
+    (c*ww + (l + r)*fw + 2^23) >> 24 with replicated edges."""
+    ww = int(np.float32(1 << 24) / np.float32(1.5))
+    fw = ((1 << 24) - ww) // 2
+
+    def passes(a):
+        a = a.astype(np.uint32)
+        for _ in range(3):
+            left = np.concatenate([a[:, :1], a[:, :-1]], axis=1)
+            right = np.concatenate([a[:, 1:], a[:, -1:]], axis=1)
+            a = (a * ww + (left + right) * fw + (1 << 23)) >> 24
+        return a
+
+    return passes(passes(img).T).T.astype(np.uint8)
+
+
+def compute_otsu(img: np.ndarray):
+    """(threshold, 0/255 mask): radius-1 Gaussian blur, Otsu, inversion when the
+    foreground exceeds half of the image, 3x3 closing then opening (reference
+    :129-188)."""
+    from PIL import Image, ImageFilter
+    from scipy import ndimage as ndi
+    blur = np.asarray(Image.fromarray(img).filter(ImageFilter.GaussianBlur(radius=1)))
+    thresh = otsu_threshold(blur)
+    mask = (blur > thresh).astype(np.uint8) * 255
+    if float(np.count_nonzero(mask) / mask.size) > 0.5:
+        mask = (255 - mask).astype(np.uint8)
+    b = mask > 127
+    b = ndi.binary_closing(b, structure=np.ones((3, 3)))
+    b = ndi.binary_opening(b, structure=np.ones((3, 3)))
+    return int(thresh), b.astype(np.uint8) * 255
+
+
+def find_largest_bbox(mask: np.ndarray):
+    """x, y, w, h of the non-zero pixels; the whole image when there are none
+    (reference :191-221)."""
+    h, w = mask.shape[:2]
+    coords = np.argwhere(mask > 0)
+    if coords.size == 0:
+        return 0, 0, w, h
+    y0, x0 = coords.min(axis=0)
+    y1, x1 = coords.max(axis=0)
+    return int(x0), int(y0), int(x1 - x0 + 1), int(y1 - y0 + 1)
+
+
+def pad_and_resize(img: np.ndarray, target: int, bg_color: str) -> np.ndarray:
+    """Aspect-preserving fit into target x target, centred on the background colour (reference :224-240)."""
+    from PIL import Image, ImageOps
+    fitted = ImageOps.contain(Image.fromarray(img), (target, target)).convert("L")
+    canvas = Image.new("L", (target, target), color=255 if bg_color == "white" else 0)
+    canvas.paste(fitted, ((target - fitted.width) // 2, (target - fitted.height) // 2))
+    return np.asarray(canvas, dtype=np.uint8)
+
+
+def clean_mask_np(mask_np: np.ndarray, resolution: int, min_size=None) -> np.ndarray:
+    """3x3 opening, then components smaller than min_size dropped (largest kept
+    when none reaches it); default min_size = max(8, 0.1 % of resolution^2)
+    (reference :246-346)."""
+    from scipy import ndimage as ndi
+    if min_size is None:
+        min_size = max(8, int(0.001 * resolution * resolution))
+    b = (mask_np > 127).astype(np.uint8)
+    b = ndi.binary_opening(b, structure=np.ones((3, 3))).astype(np.uint8)
+    labels, count = ndi.label(b)
+    if count == 0:
+        return b.astype(np.uint8) * 255
+    sizes = np.array(ndi.sum(b, labels, range(1, count + 1)))
+    keep = sizes >= min_size
+    if not keep.any():
+        keep[np.argmax(sizes)] = True
+    return np.isin(labels, 1 + np.nonzero(keep)[0]).astype(np.uint8) * 255
+
+
+def mask_to_canvas(mask: np.ndarray, resolution: int, min_size=None):
+    """Nearest resize to fit, cleaning, centred paste (reference :395-440).
+    Returns (canvas, resized width, resized height)."""
+    from PIL import Image
+    pil = Image.fromarray(mask).convert("L")
+    scale = min(resolution / float(pil.width), resolution / float(pil.height))
+    new_w = max(1, int(round(pil.width * scale)))
+    new_h = max(1, int(round(pil.height * scale)))
+    small = np.asarray(pil.resize((new_w, new_h), resample=Image.NEAREST), dtype=np.uint8)
+    small = clean_mask_np((small > 128).astype(np.uint8) * 255, resolution, min_size)
+    canvas = Image.new("L", (resolution, resolution), color=0)
+    canvas.paste(Image.fromarray(small).convert("L"), ((resolution - new_w) // 2, (resolution - new_h) // 2))
+    return np.asarray(canvas, dtype=np.uint8), new_w, new_h
+
+
+def silhouette(img: np.ndarray, resolution: int, crop_margin: float, preprocess_crop: bool, min_size=None):
+    """(cleaned 0/255 silhouette, info) of one gray view; info = [Otsu level,
+    inverted, crop x0, y0, x1, y1, resized width, height] (reference :352-440)."""
+    from PIL import Image, ImageFilter
+    h, w = img.shape[:2]
+    thresh, mask = compute_otsu(img)
+    blur = np.asarray(Image.fromarray(img).filter(ImageFilter.GaussianBlur(radius=1)))
+    inverted = int(np.count_nonzero(blur > thresh) / blur.size > 0.5)
+    x0, y0, x1, y1 = 0, 0, w, h
+    if preprocess_crop:
+        x, y, ww, hh = find_largest_bbox(mask)
+        side = max(ww, hh)
+        pad = int(round(crop_margin * side)) if crop_margin <= 1.0 else int(round(crop_margin))
+        x0, y0 = max(0, x - pad), max(0, y - pad)
+        x1, y1 = min(w, x + ww + pad), min(h, y + hh + pad)
+        if x1 <= x0 or y1 <= y0:
+            x0, y0, x1, y1 = 0, 0, w, h
+    canvas, new_w, new_h = mask_to_canvas(mask[y0:y1, x0:x1], resolution, min_size)
+    return canvas, np.array([thresh, inverted, x0, y0, x1, y1, new_w, new_h], dtype=np.int32)
+
+
+def preprocess_image(img: np.ndarray, resolution: int, crop_margin: float, bg_color: str, preprocess_crop: bool):
+    """(preprocessed gray image, cleaned 0/255 silhouette), both
+    resolution x resolution uint8 (reference :352-440)."""
+    mask, info = silhouette(img, resolution, crop_margin, preprocess_crop)
+    x0, y0, x1, y1 = (int(v) for v in info[2:6])
+    return pad_and_resize(img[y0:y1, x0:x1], resolution, bg_color), mask
+
+
 def build_c_oracle(force: bool = False) -> Path:
     so = _HERE / "libfx_oracle.so"
     src = _HERE / "fx_oracle.c"

@@ -42,7 +42,7 @@ def test_hu_directory_run(gpu, tmp_path, oracle, c_oracle, hu_panels):
     log = (rep / "read_errors.log").read_text()
     assert "view_09.png" in log and "broken" in log
     for s, sid in enumerate(ids):
-        masks = [hu.preprocess_image(hu_panels["raw_views"][s, v], 224, 0.05, "white", True)[1] for v in range(3)]
+        masks = [oracle.preprocess_image(hu_panels["raw_views"][s, v], 224, 0.05, "white", True)[1] for v in range(3)]
         rows = c_oracle.hu_batch(np.stack(masks))["hulog7"]
         want = oracle.hu_groupstat(rows)[0]
         got = df.loc[sid, hu.HU_COLS[1:15]].to_numpy(dtype=np.float64).astype(np.float32)

@@ -1,0 +1,138 @@
+"""Silhouette preprocessing on the device against the reference's outputs
+(golden) and against the oracle's PIL + scipy restatement: bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, pkg
+
+pytestmark = pytest.mark.gpu
+
+
+def run(gpu, imgs, res=224, margin=0.05, crop=True, min_size=-1):
+    eng = pkg("engine")
+    out = eng.silhouette_batch(torch.from_numpy(np.ascontiguousarray(imgs)).to(gpu), res, margin, crop, min_size,
+                               info=True)
+    torch.cuda.synchronize()
+    return out["mask"].cpu().numpy(), out["info"].cpu().numpy()
+
+
+def check(gpu, oracle, imgs, res=224, margin=0.05, crop=True, min_size=-1):
+    masks, info = run(gpu, imgs, res, margin, crop, min_size)
+    assert masks.shape == (len(imgs), res, res) and masks.dtype == np.uint8
+    for k, img in enumerate(imgs):
+        want, winfo = oracle.silhouette(img, res, margin, crop, None if min_size < 0 else min_size)
+        np.testing.assert_array_equal(info[k], winfo, err_msg=f"info of image {k}")
+        bad = np.argwhere(masks[k] != want)
+        assert bad.size == 0, f"image {k}: {len(bad)} pixels differ, first at {bad[0]}"
+
+
+def gray_scene(rng, h, w, dark_object=True, noise=12.0, blobs=4):
+    """A rendered-view look-alike: smooth blobs on a flat background + noise."""
+    yy, xx = np.mgrid[0:h, 0:w]
+    f = np.zeros((h, w))
+    for _ in range(blobs):
+        cy, cx = rng.uniform(0.2, 0.8) * h, rng.uniform(0.2, 0.8) * w
+        ry, rx = rng.uniform(0.05, 0.3) * h + 1, rng.uniform(0.05, 0.3) * w + 1
+        f = np.maximum(f, np.clip(1.5 - ((yy - cy) / ry) ** 2 - ((xx - cx) / rx) ** 2, 0, 1))
+    bg, fg = (235.0, 40.0) if dark_object else (20.0, 210.0)
+    img = bg + (fg - bg) * f + rng.normal(0, noise, (h, w))
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def test_golden_masks_of_the_reference(gpu):
+    g = np.load(GOLDEN / "preprocess_golden.npz")
+    imgs = g["inputs"]
+    for crop, tag in ((False, "nocrop"), (True, "crop")):
+        masks, info = run(gpu, imgs, 224, 0.05, crop)
+        np.testing.assert_array_equal(info[:, 0], g["otsu_thresh"])
+        np.testing.assert_array_equal(np.packbits(masks > 127, axis=2), g[f"mask_{tag}"])
+        assert set(np.unique(masks)) <= {0, 255}
+
+
+def test_view_panels_against_oracle(gpu, oracle, hu_panels):
+    raw = hu_panels["raw_views"].reshape(-1, 224, 224)
+    check(gpu, oracle, raw, 224, 0.05, True)
+    check(gpu, oracle, raw[:12], 224, 0.05, False)
+    check(gpu, oracle, raw[:12], 128, 0.2, True)
+    check(gpu, oracle, raw[:12], 256, 7.0, True)       # margin in pixels, upscaling
+
+
+@pytest.mark.parametrize("h,w,res", [(224, 224, 224), (97, 131, 100), (131, 97, 75), (512, 512, 512), (300, 480, 224),
+                                     (64, 64, 224), (33, 500, 96), (16, 16, 16)])
+def test_synthetic_scenes(gpu, oracle, h, w, res):
+    rng = np.random.default_rng(h * 1000 + w)
+    imgs = np.stack([gray_scene(rng, h, w, dark_object=bool(k & 1), noise=4.0 + 6 * k, blobs=1 + k) for k in range(6)])
+    check(gpu, oracle, imgs, res, 0.05, True)
+    check(gpu, oracle, imgs, res, 0.0, False)
+
+
+def test_noise_images_many_components(gpu, oracle):
+    """Pure noise: thousands of runs (the run table leaves LDS), many components
+    below min_size, the keep-largest rule when nothing reaches min_size."""
+    rng = np.random.default_rng(77)
+    imgs = np.stack([rng.integers(0, 256, (224, 224), dtype=np.uint8) for _ in range(4)]
+                    + [(rng.random((224, 224)) < p).astype(np.uint8) * 200 for p in (0.3, 0.45, 0.55, 0.7)])
+    check(gpu, oracle, imgs, 224, 0.05, True)
+    check(gpu, oracle, imgs, 224, 0.05, False, min_size=1)
+    check(gpu, oracle, imgs, 224, 0.05, True, min_size=100000)   # nothing reaches it: largest only
+    big = np.stack([(rng.random((512, 512)) < 0.5).astype(np.uint8) * 255 for _ in range(2)])
+    check(gpu, oracle, big, 512, 0.05, False)
+
+
+def test_degenerate_views(gpu, oracle):
+    flat = np.full((3, 224, 224), 255, dtype=np.uint8)
+    flat[1] = 0
+    flat[2, 100:103, 50:53] = 7             # 3x3 speck: survives the openings exactly
+    check(gpu, oracle, flat, 224, 0.05, True)
+    check(gpu, oracle, flat, 224, 0.05, False)
+    tiny = np.random.default_rng(3).integers(0, 256, (5, 1, 1), dtype=np.uint8)
+    check(gpu, oracle, tiny, 16, 0.05, True)
+    thin = np.random.default_rng(4).integers(0, 256, (4, 3, 200), dtype=np.uint8)
+    check(gpu, oracle, thin, 64, 0.05, True)
+    # object touching every border, and two equally large components (first in raster order wins)
+    frame = np.full((2, 96, 96), 230, dtype=np.uint8)
+    frame[0, :, :] = 30
+    frame[0, 20:70, 20:70] = 230
+    frame[1, 10:14, 10:14] = 20
+    frame[1, 60:64, 70:74] = 20
+    check(gpu, oracle, frame, 96, 0.05, False, min_size=1000)
+    check(gpu, oracle, frame, 96, 0.1, True)
+
+
+def test_padded_rows_and_empty_batch(gpu, oracle):
+    eng = pkg("engine")
+    rng = np.random.default_rng(9)
+    imgs = np.stack([gray_scene(rng, 120, 150) for _ in range(3)])
+    wide = torch.zeros((3, 120, 176), dtype=torch.uint8, device=gpu)
+    wide[:, :, :150] = torch.from_numpy(imgs).to(gpu)
+    out = eng.silhouette_batch(wide[:, :, :150], 112, 0.05, True)["mask"].cpu().numpy()
+    for k in range(3):
+        np.testing.assert_array_equal(out[k], oracle.silhouette(imgs[k], 112, 0.05, True)[0])
+    empty = eng.silhouette_batch(torch.zeros((0, 64, 64), dtype=torch.uint8, device=gpu), 32)
+    assert tuple(empty["mask"].shape) == (0, 32, 32)
+
+
+def test_rejects_unsupported_sizes(gpu):
+    eng, lib = pkg("engine"), pkg("_lib")
+    with pytest.raises(lib.FxError, match="supported up to 512x512"):
+        eng.silhouette_batch(torch.zeros((1, 513, 64), dtype=torch.uint8, device=gpu), 224)
+    with pytest.raises(lib.FxError, match="resolution"):
+        eng.silhouette_batch(torch.zeros((1, 64, 64), dtype=torch.uint8, device=gpu), 1024)
+    with pytest.raises(ValueError):
+        eng.silhouette_batch(torch.zeros((1, 64, 64), dtype=torch.float32, device=gpu), 64)
+
+
+def test_large_batch_is_deterministic_and_chunked(gpu, oracle):
+    """More views than one internal chunk of blurred scratch holds at 512x512."""
+    rng = np.random.default_rng(21)
+    base = np.stack([gray_scene(rng, 512, 512, dark_object=bool(k & 1)) for k in range(8)])
+    reps = 640                                            # 5120 views x 256 KiB > 1 GiB
+    d = torch.from_numpy(base).to(gpu).repeat(reps, 1, 1)
+    eng = pkg("engine")
+    out = eng.silhouette_batch(d, 224, 0.05, True)["mask"]
+    torch.cuda.synchronize()
+    first = out[:8].cpu().numpy()
+    for k in range(8):
+        np.testing.assert_array_equal(first[k], oracle.silhouette(base[k], 224, 0.05, True)[0])
+    assert torch.equal(out.view(reps, 8, 224, 224), out[:8].unsqueeze(0).expand(reps, -1, -1, -1))

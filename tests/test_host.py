@@ -13,24 +13,7 @@ import pytest
 from conftest import GOLDEN, ROOT, pkg
 
 
-# ------------------------------------------------------------ preprocessing
-def test_preprocess_matches_reference_outputs():
-    """preprocess_golden.npz holds what the reference's preprocess_image /
-    compute_otsu return (its PIL + scipy branch) for eight raw view panels."""
-    hu = pkg("extract_2d_hu")
-    g = np.load(GOLDEN / "preprocess_golden.npz")
-    for i, img in enumerate(g["inputs"]):
-        t, m = hu.compute_otsu(img.copy())
-        assert t == int(g["otsu_thresh"][i])
-        np.testing.assert_array_equal(np.packbits(m > 127, axis=1), g["otsu_mask"][i])
-        assert set(np.unique(m)) <= {0, 255}
-        for crop, tag in ((False, "nocrop"), (True, "crop")):
-            pre, mask = hu.preprocess_image(img.copy(), 224, 0.05, "white", crop)
-            assert pre.shape == mask.shape == (224, 224) and pre.dtype == mask.dtype == np.uint8
-            np.testing.assert_array_equal(pre, g[f"preproc_{tag}"][i])
-            np.testing.assert_array_equal(np.packbits(mask > 127, axis=1), g[f"mask_{tag}"][i])
-
-
+# ------------------------------------------------------------ host helpers
 def test_list_sample_ids_and_views(tmp_path):
     from PIL import Image
     hu = pkg("extract_2d_hu")

@@ -125,3 +125,33 @@ def test_empty_and_degenerate_hu(oracle, c_oracle):
     r = c_oracle.hu_batch(one)
     assert r["moments24"][0, 0] == 200 and r["moments24"][0, 1] == 800 and r["moments24"][0, 2] == 600
     assert np.all(r["hu7"] == 0) and np.all(r["hulog7"] == 0)
+
+
+# ------------------------------------------------------------ silhouette preprocessing
+def test_silhouette_restatement_equals_reference_outputs(oracle):
+    """preprocess_golden.npz holds what the reference's preprocess_image /
+    compute_otsu return (its PIL + scipy branch) for eight raw view panels."""
+    g = np.load(GOLDEN / "preprocess_golden.npz")
+    for i, img in enumerate(g["inputs"]):
+        t, m = oracle.compute_otsu(img.copy())
+        assert t == int(g["otsu_thresh"][i])
+        np.testing.assert_array_equal(np.packbits(m > 127, axis=1), g["otsu_mask"][i])
+        assert set(np.unique(m)) <= {0, 255}
+        for crop, tag in ((False, "nocrop"), (True, "crop")):
+            pre, mask = oracle.preprocess_image(img.copy(), 224, 0.05, "white", crop)
+            assert pre.shape == mask.shape == (224, 224) and pre.dtype == mask.dtype == np.uint8
+            np.testing.assert_array_equal(pre, g[f"preproc_{tag}"][i])
+            np.testing.assert_array_equal(np.packbits(mask > 127, axis=1), g[f"mask_{tag}"][i])
+            sil, info = oracle.silhouette(img.copy(), 224, 0.05, crop)
+            np.testing.assert_array_equal(sil, mask)
+            assert info[0] == t and 0 <= info[2] < info[4] <= img.shape[1] and 0 <= info[3] < info[5] <= img.shape[0]
+
+
+def test_pil_gaussian_blur_written_out(oracle):
+    """The integer form of PIL's GaussianBlur(radius=1) that the device kernel follows."""
+    from PIL import Image, ImageFilter
+    rng = np.random.default_rng(5)
+    for shape in ((224, 224), (37, 91), (1, 5), (5, 1), (2, 2), (300, 512), (1, 1)):
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        ref = np.asarray(Image.fromarray(img).filter(ImageFilter.GaussianBlur(radius=1)))
+        np.testing.assert_array_equal(oracle.pil_gaussian_blur_r1(img), ref)
