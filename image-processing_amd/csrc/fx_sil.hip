@@ -8,7 +8,7 @@
 // Otsu criterion and the resize geometry, which are IEEE float64 in the
 // reference's operation order.
 //
-//   sil_blur_kernel   a block per 32-row tile: the six 3-tap passes of PIL's
+//   sil_blur_kernel   a block per tile of rows: the six 3-tap passes of PIL's
 //                     radius-1 Gaussian (three along x in registers, three
 //                     along y from an LDS tile), blurred bytes + 256-bin
 //                     histogram to scratch.
@@ -20,11 +20,10 @@
 
 namespace {
 
-constexpr int SIL_TR = 32;    // output rows per blur tile
-constexpr int SIL_HALO = 3;   // three 3-tap passes
-constexpr int SIL_TROWS = SIL_TR + 2 * SIL_HALO;
+constexpr int SIL_HALO = 3;         // three 3-tap passes
+constexpr int SIL_MAX_TROWS = 64;   // rows of a blur tile, halo included
 constexpr int SIL_MAX_SIDE = 512;
-constexpr int SIL_RUNS_LDS = 2048;  // run table kept in LDS up to this many runs
+constexpr int SIL_RUNS_LDS = 1024;  // run table kept in LDS up to this many runs
 constexpr int SIL_MAX_GRID = 1536;
 
 // PIL's box blur for GaussianBlur(radius=1): three passes of a box of radius
@@ -51,6 +50,7 @@ struct SilArgs {
     int run_cap;
     int wpr;          // words per row of the LDS masks
     int rows;         // rows of the LDS masks
+    int tr;           // output rows per blur tile
 };
 
 __device__ __forceinline__ uint32_t sil_tap(uint32_t l, uint32_t c, uint32_t r)
@@ -58,24 +58,47 @@ __device__ __forceinline__ uint32_t sil_tap(uint32_t l, uint32_t c, uint32_t r)
     return (c * SIL_WW + (l + r) * SIL_FW + (1u << 23)) >> 24;
 }
 
+// The three passes along a row on 22 pixels held in registers (16 + 3 on each
+// side, v[k] is pixel x0 - 3 + k).  EDGE: the row's first or last pixel is
+// among them; the neighbour of an edge pixel is the pixel itself.
+template <bool EDGE>
+__device__ __forceinline__ void sil_row_passes(uint32_t (&v)[22], int x0, int W)
+{
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+        uint32_t n[22];
+#pragma unroll
+        for (int k = 1 + p; k <= 20 - p; k++) {
+            const int x = x0 - 3 + k;
+            const uint32_t l = EDGE && x - 1 < 0 ? v[k] : v[k - 1];
+            const uint32_t r = EDGE && x + 1 > W - 1 ? v[k] : v[k + 1];
+            n[k] = sil_tap(l, v[k], r);
+        }
+#pragma unroll
+        for (int k = 1 + p; k <= 20 - p; k++)
+            v[k] = n[k];
+    }
+}
+
 template <bool ALIGNED>
 __global__ __launch_bounds__(FX_BLOCK) void sil_blur_kernel(SilArgs A)
 {
     extern __shared__ __align__(16) uint8_t sil_smem[];
     const int Wp = (A.W + 15) & ~15;
-    uint8_t *tile = sil_smem;                                    // [SIL_TROWS][Wp]
-    uint32_t *hist = (uint32_t *)(sil_smem + SIL_TROWS * Wp);    // [256]
+    const int trows = A.tr + 2 * SIL_HALO;
+    uint8_t *tile = sil_smem;                                // [trows][Wp]
+    uint32_t *hist = (uint32_t *)(sil_smem + trows * Wp);    // [256]
     const int64_t b = blockIdx.y;
-    const int r0 = blockIdx.x * SIL_TR;
+    const int r0 = blockIdx.x * A.tr;
     const uint8_t *src = A.img + b * A.stride;
     const int cpr = Wp >> 4;
     hist[threadIdx.x] = 0;
     // tile row i holds image row r0 - SIL_HALO + i; rows [ilo, ihi] exist
     const int ilo = SIL_HALO - r0 > 0 ? SIL_HALO - r0 : 0;
-    const int ihi = A.H - 1 - r0 + SIL_HALO < SIL_TROWS - 1 ? A.H - 1 - r0 + SIL_HALO : SIL_TROWS - 1;
+    const int ihi = A.H - 1 - r0 + SIL_HALO < trows - 1 ? A.H - 1 - r0 + SIL_HALO : trows - 1;
 
     // three passes along x: 16 pixels + 3 on each side in registers
-    for (int it = threadIdx.x; it < SIL_TROWS * cpr; it += FX_BLOCK) {
+    for (int it = threadIdx.x; it < trows * cpr; it += FX_BLOCK) {
         const int i = it / cpr, c = it - i * cpr;
         if (i < ilo || i > ihi)
             continue;
@@ -104,21 +127,10 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_blur_kernel(SilArgs A)
                 v[k] = row[x];
             }
         }
-#pragma unroll
-        for (int p = 0; p < 3; p++) {
-            uint32_t n[22];
-#pragma unroll
-            for (int k = 1 + p; k <= 20 - p; k++) {
-                const int x = x0 - 3 + k;
-                // the neighbour of an edge pixel is the pixel itself
-                const uint32_t l = x - 1 < 0 ? v[k] : v[k - 1];
-                const uint32_t r = x + 1 > A.W - 1 ? v[k] : v[k + 1];
-                n[k] = sil_tap(l, v[k], r);
-            }
-#pragma unroll
-            for (int k = 1 + p; k <= 20 - p; k++)
-                v[k] = n[k];
-        }
+        if (x0 >= 3 && x0 + 18 <= A.W - 1)
+            sil_row_passes<false>(v, x0, A.W);
+        else
+            sil_row_passes<true>(v, x0, A.W);
         uint4 o;
         o.x = v[3] | (v[4] << 8) | (v[5] << 16) | (v[6] << 24);
         o.y = v[7] | (v[8] << 8) | (v[9] << 16) | (v[10] << 24);
@@ -128,33 +140,57 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_blur_kernel(SilArgs A)
     }
     __syncthreads();
 
-    // three passes along y: a thread per column, the column in registers
+    // three passes along y: a thread per column walks down the tile; the
+    // passes run as a pipeline, pass k one row behind pass k - 1.  Row i of
+    // the result needs rows i - 3 .. i + 3 of the tile, or fewer at the image's
+    // first and last row, where a pixel stands in for its missing neighbour.
     uint8_t *dst = A.blur + b * (int64_t)A.H * A.W;
+    const int olo = ilo > SIL_HALO ? ilo : SIL_HALO;                        // rows this tile writes
+    const int ohi = ihi < trows - 1 - SIL_HALO ? ihi : trows - 1 - SIL_HALO;
     for (int x = threadIdx.x; x < A.W; x += FX_BLOCK) {
-        uint32_t c[SIL_TROWS];
-#pragma unroll
-        for (int i = 0; i < SIL_TROWS; i++)
-            c[i] = tile[i * Wp + x];
-#pragma unroll
-        for (int p = 0; p < 3; p++) {
-            uint32_t n[SIL_TROWS];
-#pragma unroll
-            for (int i = 1 + p; i <= SIL_TROWS - 2 - p; i++) {
-                const uint32_t up = i - 1 < ilo ? c[i] : c[i - 1];
-                const uint32_t dn = i + 1 > ihi ? c[i] : c[i + 1];
-                n[i] = sil_tap(up, c[i], dn);
-            }
-#pragma unroll
-            for (int i = 1 + p; i <= SIL_TROWS - 2 - p; i++)
-                c[i] = n[i];
-        }
-#pragma unroll
-        for (int i = SIL_HALO; i < SIL_HALO + SIL_TR; i++) {
+        const uint8_t *col = tile + x;
+        uint32_t c0 = 0, c1 = col[ilo * Wp], c2 = ilo + 1 <= ihi ? col[(ilo + 1) * Wp] : c1;  // input rows i-1, i, i+1
+        uint32_t p1a = 0, p1b = 0, p1c = 0;   // pass 1 at rows i-2, i-1, i
+        uint32_t p2a = 0, p2b = 0, p2c = 0;   // pass 2 at rows i-3, i-2, i-1
+        uint32_t run_v = 0, run_n = 0;
+        for (int i = ilo; i <= ihi + 2; i++) {
+            const uint32_t c3 = i + 2 <= ihi ? col[(i + 2) * Wp] : 0u;  // prefetch of row i + 2
             if (i <= ihi) {
-                dst[(int64_t)(r0 - SIL_HALO + i) * A.W + x] = (uint8_t)c[i];
-                atomicAdd(&hist[c[i]], 1u);
+                const uint32_t up = i - 1 < ilo ? c1 : c0, dn = i + 1 > ihi ? c1 : c2;
+                p1a = p1b;
+                p1b = p1c;
+                p1c = sil_tap(up, c1, dn);
             }
+            if (i - 1 >= ilo && i - 1 <= ihi) {
+                // pass 2 at row i - 1 from pass 1 at rows i - 2, i - 1, i
+                const uint32_t mid = i <= ihi ? p1b : p1c;
+                const uint32_t above = i <= ihi ? p1a : p1b;
+                const uint32_t up = i - 2 < ilo ? mid : above, dn = i > ihi ? mid : p1c;
+                p2a = p2b;
+                p2b = p2c;
+                p2c = sil_tap(up, mid, dn);
+            }
+            if (i - 2 >= olo && i - 2 <= ohi) {
+                // pass 3 at row i - 2 from pass 2 at rows i - 3, i - 2, i - 1
+                const uint32_t mid = i - 1 <= ihi ? p2b : p2c;
+                const uint32_t above = i - 1 <= ihi ? p2a : p2b;
+                const uint32_t up = i - 3 < ilo ? mid : above, dn = i - 1 > ihi ? mid : p2c;
+                const uint32_t v = sil_tap(up, mid, dn);
+                dst[(int64_t)(r0 - SIL_HALO + i - 2) * A.W + x] = (uint8_t)v;
+                // neighbouring rows mostly share a value: one LDS atomic per stretch
+                if (v != run_v && run_n) {
+                    atomicAdd(&hist[run_v], run_n);
+                    run_n = 0;
+                }
+                run_v = v;
+                run_n++;
+            }
+            c0 = c1;
+            c1 = c2;
+            c2 = c3;
         }
+        if (run_n)
+            atomicAdd(&hist[run_v], run_n);
     }
     __syncthreads();
     const uint32_t h = hist[threadIdx.x];
@@ -171,50 +207,70 @@ __device__ void sil_morph(const uint32_t *s, uint32_t *d, int rows, int cols, in
 {
     const int wc = (cols + 31) >> 5;
     const uint32_t lastmask = (cols & 31) ? ((1u << (cols & 31)) - 1u) : ~0u;
-    for (int wi = threadIdx.x; wi < rows * wc; wi += FX_BLOCK) {
-        const int y = wi / wc, w = wi - y * wc;
-        uint32_t acc = DILATE ? 0u : ~0u;
-#pragma unroll
-        for (int dy = -1; dy <= 1; dy++) {
-            const int yy = y + dy;
-            uint32_t h = 0u;
-            if (yy >= 0 && yy < rows) {
-                const uint32_t *r = s + yy * wpr;
-                const uint32_t m = r[w];
-                const uint32_t p = w > 0 ? r[w - 1] : 0u;
-                const uint32_t n = w + 1 < wc ? r[w + 1] : 0u;
-                const uint32_t L = (m << 1) | (p >> 31), R = (m >> 1) | (n << 31);
-                h = DILATE ? (m | L | R) : (m & L & R);
-            }
-            acc = DILATE ? (acc | h) : (acc & h);
+    // strips of `rs` rows of one word column per thread: a row's horizontal
+    // combination is computed once and used for three output rows
+    int strips = FX_BLOCK / wc;
+    strips = strips < 1 ? 1 : strips;
+    const int rs = (rows + strips - 1) / strips;
+    for (int it = threadIdx.x; it < wc * strips; it += FX_BLOCK) {
+        const int w = it % wc, y0 = (it / wc) * rs;
+        if (y0 >= rows)
+            continue;
+        const int y1 = y0 + rs < rows ? y0 + rs : rows;
+        auto hrow = [&](int yy) -> uint32_t {
+            if (yy < 0 || yy >= rows)
+                return 0u;  // outside is background for both operations
+            const uint32_t *r = s + yy * wpr;
+            const uint32_t m = r[w];
+            const uint32_t p = w > 0 ? r[w - 1] : 0u;
+            const uint32_t n = w + 1 < wc ? r[w + 1] : 0u;
+            const uint32_t L = (m << 1) | (p >> 31), R = (m >> 1) | (n << 31);
+            return DILATE ? (m | L | R) : (m & L & R);
+        };
+        uint32_t ha = hrow(y0 - 1), hb = hrow(y0);
+        for (int y = y0; y < y1; y++) {
+            const uint32_t hc = hrow(y + 1);
+            uint32_t acc = DILATE ? (ha | hb | hc) : (ha & hb & hc);
+            if (w == wc - 1)
+                acc &= lastmask;
+            d[y * wpr + w] = acc;
+            ha = hb;
+            hb = hc;
         }
-        if (w == wc - 1)
-            acc &= lastmask;
-        d[y * wpr + w] = acc;
     }
     __syncthreads();
 }
 
-__device__ __forceinline__ uint32_t sil_find(volatile uint32_t *parent, uint32_t a)
+// Root of a run.  Parents only ever decrease, so a node may be pointed at its
+// grandparent on the way up (path halving) while other lanes unite.
+__device__ __forceinline__ uint32_t sil_find(uint32_t *parent, uint32_t a)
 {
-    uint32_t p;
-    while ((p = parent[a]) != a)
+    volatile uint32_t *vp = parent;
+    uint32_t p = vp[a];
+    while (p != a) {
+        const uint32_t g = vp[p];
+        if (g != p)
+            atomicMin(&parent[a], g);
         a = p;
+        p = g;
+    }
     return a;
 }
 
-// Lock-free union, the smaller index becomes the root.
+// Lock-free union.  A root is the smallest index of its tree and may be hung
+// below any smaller node of the other tree, so the usual case (a run and the
+// run above it) is one read and one atomic, without climbing.
 __device__ void sil_unite(uint32_t *parent, uint32_t a, uint32_t b)
 {
     for (;;) {
         a = sil_find(parent, a);
-        b = sil_find(parent, b);
         if (a == b)
             return;
-        if (a < b) {
+        if (a < b) {  // b may still belong to a's tree: climb from b instead
             const uint32_t t = a;
             a = b;
             b = t;
+            continue;
         }
         const uint32_t old = atomicMin(&parent[a], b);
         if (old == a)
@@ -226,21 +282,49 @@ __device__ void sil_unite(uint32_t *parent, uint32_t a, uint32_t b)
 // bits of m up to and including position `bit`
 __device__ __forceinline__ uint32_t sil_le(int bit) { return bit >= 31 ? ~0u : ((2u << bit) - 1u); }
 
+// Four bytes of d compared with k = 128 * kh + kl (1 <= k <= 255) at once:
+// bit j of the result is set when byte j >= k.  kl4 = kl * 0x01010101.
+__device__ __forceinline__ uint32_t sil_ge4(uint32_t d, uint32_t kl4, bool kh)
+{
+    const uint32_t t = ((d & 0x7f7f7f7fu) | 0x80808080u) - kl4;  // bit 7 of a byte: low 7 bits >= kl
+    const uint32_t m = ((kh ? (d & t) : (d | t)) & 0x80808080u) >> 7;
+    return (m | (m >> 7) | (m >> 14) | (m >> 21)) & 0xFu;
+}
+
+// Four mask bits to four bytes of 0 / 255.
+__device__ __forceinline__ uint32_t sil_spread4(uint32_t nib)
+{
+    return (__umul24(nib, 0x00204081u) & 0x01010101u) * 255u;
+}
+
+#ifdef SIL_TIMING
+#define SIL_TICK(n)                                        \
+    do {                                                   \
+        if (t == 0 && blockIdx.x == 0 && b == 0)           \
+            s_tick[n] = __builtin_readcyclecounter();      \
+    } while (0)
+#else
+#define SIL_TICK(n)
+#endif
+
 enum {
     SV_COUNT = 0, SV_THRESH, SV_INV, SV_MINX, SV_MINY, SV_MAXX, SV_MAXY, SV_CX0, SV_CY0, SV_CW, SV_CH, SV_NW,
-    SV_NH, SV_NRUNS, SV_ANYKEEP, SV_N
+    SV_NH, SV_NRUNS, SV_ANYKEEP, SV_NEAR, SV_N
 };
 
 __global__ __launch_bounds__(FX_BLOCK) void sil_mask_kernel(SilArgs A)
 {
     extern __shared__ __align__(16) uint8_t sil_smem[];
-    __shared__ double s_between[256];
+    __shared__ double s_between[FX_WAVES_PER_BLOCK];
     __shared__ uint32_t s_hist[256];
-    __shared__ uint32_t s_scan[256];
-    __shared__ uint16_t s_xtab[SIL_MAX_SIDE], s_ytab[SIL_MAX_SIDE];
+    __shared__ uint32_t s_scan[16 + 256];
+    __shared__ uint16_t s_xtab[SIL_MAX_SIDE + 32], s_ytab[SIL_MAX_SIDE];
     __shared__ uint32_t s_parent[SIL_RUNS_LDS], s_size[SIL_RUNS_LDS];
     __shared__ int s_v[SV_N];
     __shared__ unsigned long long s_best;
+#ifdef SIL_TIMING
+    __shared__ unsigned long long s_tick[24];
+#endif
 
     const int t = threadIdx.x;
     const int nw = A.rows * A.wpr;
@@ -260,17 +344,34 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_mask_kernel(SilArgs A)
         if (t == 0)
             s_best = 0ull;
         __syncthreads();
+        SIL_TICK(0);
         {
-            u64 wb = 0, sb = 0, wt = 0;
-            for (int k = 0; k < 256; k++) {
-                const u64 h = s_hist[k];
-                wt += (u64)k * h;
-                if (k <= t) {
-                    wb += h;
-                    sb += (u64)k * h;
+            // inclusive prefix sums of the counts and of level * count (both below 2^32)
+            const int lane = fx_lane(), wave = fx_wave();
+            uint32_t wb = s_hist[t], sb = (uint32_t)t * wb;
+#pragma unroll
+            for (int o = 1; o < FX_WAVE; o <<= 1) {
+                const uint32_t uc = __shfl_up(wb, o, FX_WAVE), us = __shfl_up(sb, o, FX_WAVE);
+                if (lane >= o) {
+                    wb += uc;
+                    sb += us;
                 }
             }
-            const u64 total = (u64)H * (u64)W;
+            if (lane == FX_WAVE - 1) {
+                s_scan[wave] = wb;
+                s_scan[4 + wave] = sb;
+            }
+            __syncthreads();
+            uint32_t wt = 0;
+#pragma unroll
+            for (int w = 0; w < FX_WAVES_PER_BLOCK; w++) {
+                if (w < wave) {
+                    wb += s_scan[w];
+                    sb += s_scan[4 + w];
+                }
+                wt += s_scan[4 + w];
+            }
+            const uint32_t total = (uint32_t)(H * W);
             double between = -1.0;  // level not considered
             if (wb > 0 && total - wb > 0) {
                 const double w_back = (double)wb, w_fore = (double)(total - wb);
@@ -279,48 +380,94 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_mask_kernel(SilArgs A)
                 const double d = m_back - m_fore;
                 between = ((w_back * w_fore) * d) * d;
             }
-            s_between[t] = between;
-        }
-        __syncthreads();
-        if (t == 0) {
-            double best = 0.0;
-            int level = 0;
-            for (int i = 0; i < 256; i++) {
-                const double bt = s_between[i];
-                if (bt >= 0.0 && bt >= best) {  // ties go to the higher level
-                    best = bt;
-                    level = i;
+            // largest criterion, the higher level among equals (`>=` in the reference's loop)
+            int level = t;
+#pragma unroll
+            for (int o = FX_WAVE / 2; o > 0; o >>= 1) {
+                const double ob = __shfl_xor(between, o, FX_WAVE);
+                const int ol = __shfl_xor(level, o, FX_WAVE);
+                if (ob > between || (ob == between && ol > level)) {
+                    between = ob;
+                    level = ol;
                 }
             }
-            s_v[SV_THRESH] = level;
+            if (lane == 0) {
+                s_between[wave] = between;
+                s_scan[8 + wave] = (uint32_t)level;
+            }
+            __syncthreads();
+            if (t == 0) {
+                double best = -1.0;
+                int lv = 0;
+#pragma unroll
+                for (int w = 0; w < FX_WAVES_PER_BLOCK; w++) {
+                    if (s_between[w] >= 0.0 && s_between[w] >= best) {  // waves hold ascending levels
+                        best = s_between[w];
+                        lv = (int)s_scan[8 + w];
+                    }
+                }
+                s_v[SV_THRESH] = lv;
+            }
         }
         __syncthreads();
         const uint32_t thresh = (uint32_t)s_v[SV_THRESH];
 
         // ---- bit mask of blur > thresh
         const uint8_t *blur = A.blur + b * (int64_t)H * W;
+        SIL_TICK(1);
         {
             uint32_t cnt = 0;
-            for (int wi = t; wi < H * wcH; wi += FX_BLOCK) {
-                const int y = wi / wcH, w = wi - y * wcH;
-                const uint8_t *p = blur + (int64_t)y * W + 32 * w;
-                uint32_t word = 0;
-                if ((W & 15) == 0) {
-                    const int nq = 32 * w + 16 < W ? 2 : 1;
-                    for (int q = 0; q < nq; q++) {
-                        const uint4 m = *(const uint4 *)(p + 16 * q);
-                        const uint32_t mw[4] = {m.x, m.y, m.z, m.w};
+            const uint32_t kcmp = thresh + 1u;  // pixel > thresh  <=>  pixel >= kcmp
+            const uint32_t kl4 = (kcmp & 127u) * 0x01010101u;
+            const bool kh = (kcmp & 128u) != 0;
+            if ((W & 15) == 0) {
+                for (int w0 = t; w0 < H * wcH; w0 += 4 * FX_BLOCK) {
+                    uint4 q[4][2];
 #pragma unroll
-                        for (int k = 0; k < 16; k++)
-                            word |= (((mw[k >> 2] >> (8 * (k & 3))) & 255u) > thresh ? 1u : 0u) << (16 * q + k);
+                    for (int j = 0; j < 4; j++) {
+                        const int wi = w0 + j * FX_BLOCK;
+                        q[j][0] = q[j][1] = make_uint4(0u, 0u, 0u, 0u);
+                        if (wi < H * wcH) {
+                            const int y = wi / wcH, w = wi - y * wcH;
+                            const uint8_t *p = blur + (int64_t)y * W + 32 * w;
+                            q[j][0] = *(const uint4 *)p;
+                            if (32 * w + 16 < W)
+                                q[j][1] = *(const uint4 *)(p + 16);
+                        }
                     }
-                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int wi = w0 + j * FX_BLOCK;
+                        if (wi < H * wcH) {
+                            const int y = wi / wcH, w = wi - y * wcH;
+                            uint32_t word = 0;
+                            if (kcmp <= 255u) {
+#pragma unroll
+                                for (int h = 0; h < 2; h++)
+                                    word |= (sil_ge4(q[j][h].x, kl4, kh) | (sil_ge4(q[j][h].y, kl4, kh) << 4) |
+                                             (sil_ge4(q[j][h].z, kl4, kh) << 8) | (sil_ge4(q[j][h].w, kl4, kh) << 12))
+                                            << (16 * h);
+                                // a zero-filled second half reads as "not above" unless kcmp == 0, which cannot be
+                            }
+                            mA[y * wpr + w] = word;
+                            cnt += __popc(word);
+                        }
+                    }
+                }
+            } else {
+                for (int wi = t; wi < H * wcH; wi += FX_BLOCK) {
+                    const int y = wi / wcH, w = wi - y * wcH;
+                    const uint8_t *p = blur + (int64_t)y * W + 32 * w;
+                    uint32_t word = 0;
                     for (int k = 0; k < 32 && 32 * w + k < W; k++)
                         word |= (p[k] > thresh ? 1u : 0u) << k;
+                    mA[y * wpr + w] = word;
+                    cnt += __popc(word);
                 }
-                mA[y * wpr + w] = word;
-                cnt += __popc(word);
             }
+            cnt = (uint32_t)fx_wave_sum_u64(cnt);
+            if (fx_lane() != 0)
+                cnt = 0;
             if (cnt)
                 atomicAdd(&s_v[SV_COUNT], (int)cnt);
         }
@@ -338,12 +485,14 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_mask_kernel(SilArgs A)
         }
         __syncthreads();
 
+        SIL_TICK(2);
         // ---- 3x3 closing then opening (reference :170-186)
         sil_morph<true>(mA, mB, H, W, wpr);
         sil_morph<false>(mB, mA, H, W, wpr);
         sil_morph<false>(mA, mB, H, W, wpr);
         sil_morph<true>(mB, mA, H, W, wpr);
 
+        SIL_TICK(3);
         // ---- bounding box of the foreground (reference :191-221, branch without cv2)
         {
             int mnx = W, mny = H, mxx = -1, mxy = -1;
@@ -358,7 +507,16 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_mask_kernel(SilArgs A)
                     mxy = y > mxy ? y : mxy;
                 }
             }
-            if (mxx >= 0) {
+#pragma unroll
+            for (int o = FX_WAVE / 2; o > 0; o >>= 1) {
+                const int a = __shfl_xor(mnx, o, FX_WAVE), b2 = __shfl_xor(mny, o, FX_WAVE);
+                const int c = __shfl_xor(mxx, o, FX_WAVE), d2 = __shfl_xor(mxy, o, FX_WAVE);
+                mnx = a < mnx ? a : mnx;
+                mny = b2 < mny ? b2 : mny;
+                mxx = c > mxx ? c : mxx;
+                mxy = d2 > mxy ? d2 : mxy;
+            }
+            if (fx_lane() == 0 && mxx >= 0) {
                 atomicMin(&s_v[SV_MINX], mnx);
                 atomicMin(&s_v[SV_MINY], mny);
                 atomicMax(&s_v[SV_MAXX], mxx);
@@ -367,6 +525,7 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_mask_kernel(SilArgs A)
         }
         __syncthreads();
 
+        SIL_TICK(4);
         // ---- crop rectangle and target size (reference :352-440)
         if (t == 0) {
             int x0 = 0, y0 = 0, x1 = W, y1 = H;
@@ -409,21 +568,46 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_mask_kernel(SilArgs A)
         __syncthreads();
         const int cx0 = s_v[SV_CX0], cy0 = s_v[SV_CY0], cw = s_v[SV_CW], ch = s_v[SV_CH];
         const int new_w = s_v[SV_NW], new_h = s_v[SV_NH];
+        SIL_TICK(5);
         // PIL's nearest resize steps through the source with a float64
         // accumulator: xo = a/2, then xo += a per output pixel.
-        if (t == 0 || t == FX_WAVE) {
-            const int n_out = t == 0 ? new_w : new_h, n_in = t == 0 ? cw : ch;
-            uint16_t *tab = t == 0 ? s_xtab : s_ytab;
-            const double a = (double)n_in / (double)n_out;
-            double xo = a * 0.5;
-            for (int x = 0; x < n_out; x++) {
-                const int xin = (int)xo;
-                tab[x] = xin < n_in ? (uint16_t)xin : (uint16_t)0xFFFF;
-                xo += a;
+        // Every entry is int(xo).  The accumulated xo differs from (x + 0.5) * a
+        // by less than 1e-10, so the product decides unless it lies that close
+        // to an integer; then the table is stepped through in order.
+        {
+            const double ax = (double)cw / (double)new_w, ay = (double)ch / (double)new_h;
+            int near = 0;
+            for (int x = t; x < ((new_w + 31) & ~31); x += FX_BLOCK) {
+                const double v = ((double)x + 0.5) * ax;
+                const int xin = (int)v;
+                near |= fabs(v - rint(v)) < 1e-9 ? 1 : 0;
+                s_xtab[x] = x < new_w && xin < cw ? (uint16_t)xin : (uint16_t)0xFFFF;
+            }
+            for (int y = t; y < new_h; y += FX_BLOCK) {
+                const double v = ((double)y + 0.5) * ay;
+                const int yin = (int)v;
+                near |= fabs(v - rint(v)) < 1e-9 ? 2 : 0;
+                s_ytab[y] = yin < ch ? (uint16_t)yin : (uint16_t)0xFFFF;
+            }
+            if (near)
+                atomicOr(&s_v[SV_NEAR], near);
+            __syncthreads();
+            const int flags = s_v[SV_NEAR];
+            if ((t == 0 && (flags & 1)) || (t == FX_WAVE && (flags & 2))) {
+                const int n_out = t == 0 ? new_w : new_h, n_in = t == 0 ? cw : ch;
+                uint16_t *tab = t == 0 ? s_xtab : s_ytab;
+                const double a = t == 0 ? ax : ay;
+                double xo = a * 0.5;
+                for (int x = 0; x < n_out; x++) {
+                    const int xin = (int)xo;
+                    tab[x] = xin < n_in ? (uint16_t)xin : (uint16_t)0xFFFF;
+                    xo += a;
+                }
             }
         }
         __syncthreads();
 
+        SIL_TICK(6);
         // ---- resized mask (new_h x new_w) into mB
         const int wcS = (new_w + 31) >> 5;
         for (int wi = t; wi < new_h * wcS; wi += FX_BLOCK) {
@@ -432,22 +616,27 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_mask_kernel(SilArgs A)
             uint32_t word = 0;
             if (sy != 0xFFFFu) {
                 const uint32_t *r = mA + (cy0 + (int)sy) * wpr;
-                for (int k = 0; k < 32 && 32 * w + k < new_w; k++) {
-                    const uint32_t sx = s_xtab[32 * w + k];
-                    if (sx != 0xFFFFu) {
-                        const int x = cx0 + (int)sx;
-                        word |= ((r[x >> 5] >> (x & 31)) & 1u) << k;
-                    }
+                uint32_t sx[32];
+#pragma unroll
+                for (int k = 0; k < 32; k++)
+                    sx[k] = s_xtab[32 * w + k];
+#pragma unroll
+                for (int k = 0; k < 32; k++) {
+                    const int x = cx0 + (int)(sx[k] == 0xFFFFu ? 0u : sx[k]);
+                    const uint32_t bit = (r[x >> 5] >> (x & 31)) & 1u;
+                    word |= (sx[k] == 0xFFFFu ? 0u : bit) << k;
                 }
             }
             mB[y * wpr + w] = word;
         }
         __syncthreads();
 
+        SIL_TICK(7);
         // ---- 3x3 opening of the resized mask (reference :246-346)
         sil_morph<false>(mB, mA, new_h, new_w, wpr);
         sil_morph<true>(mA, mB, new_h, new_w, wpr);
 
+        SIL_TICK(8);
         // ---- 4-connected components over row runs
         // A run is named by the raster-order rank of its first pixel: the run
         // that holds a set pixel is the latest run started at or before it.
@@ -464,15 +653,25 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_mask_kernel(SilArgs A)
                     local += __popc(m & ~((m << 1) | (p >> 31)));
                 }
             }
-            s_scan[t] = local;
+            // exclusive prefix over the block: wave scan, then the waves in front
+            uint32_t inc = local;
+#pragma unroll
+            for (int o = 1; o < FX_WAVE; o <<= 1) {
+                const uint32_t u = __shfl_up(inc, o, FX_WAVE);
+                if (fx_lane() >= o)
+                    inc += u;
+            }
+            if (fx_lane() == FX_WAVE - 1)
+                s_scan[fx_wave()] = inc;
+            s_scan[16 + t] = inc - local;
         }
         __syncthreads();
         {
-            uint32_t base = 0, total = 0;
-            for (int k = 0; k < FX_BLOCK; k++) {
-                const uint32_t v = s_scan[k];
-                base += k < t ? v : 0u;
-                total += v;
+            uint32_t base = s_scan[16 + t], total = 0;
+#pragma unroll
+            for (int w = 0; w < FX_WAVES_PER_BLOCK; w++) {
+                base += w < fx_wave() ? s_scan[w] : 0u;
+                total += s_scan[w];
             }
             for (int j = 0; j < per; j++) {
                 const int wi = t * per + j;
@@ -496,6 +695,7 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_mask_kernel(SilArgs A)
             rsize[r] = 0u;
         }
         __syncthreads();
+        SIL_TICK(9);
         // runs of neighbouring rows that share a column belong together
         for (int wi = t + wcS; wi < nwS; wi += FX_BLOCK) {
             const int y = wi / wcS, w = wi - y * wcS;
@@ -516,10 +716,22 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_mask_kernel(SilArgs A)
         }
         __threadfence_block();
         __syncthreads();
-        for (int r = t; r < nruns; r += FX_BLOCK)
-            parent[r] = sil_find(parent, (uint32_t)r);
-        __threadfence_block();
-        __syncthreads();
+        // every run to its root: pointer jumping, the depth halves per round
+        for (;;) {
+            int changed = 0;
+            for (int r = t; r < nruns; r += FX_BLOCK) {
+                const uint32_t q = ((volatile uint32_t *)parent)[r];
+                const uint32_t g = ((volatile uint32_t *)parent)[q];
+                if (g != q) {
+                    parent[r] = g;
+                    changed = 1;
+                }
+            }
+            __threadfence_block();
+            if (!__syncthreads_or(changed))
+                break;
+        }
+        SIL_TICK(10);
         // component sizes
         for (int wi = t; wi < nwS; wi += FX_BLOCK) {
             const int y = wi / wcS, w = wi - y * wcS;
@@ -540,6 +752,7 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_mask_kernel(SilArgs A)
         }
         __threadfence_block();
         __syncthreads();
+        SIL_TICK(11);
         // keep components of at least min_size pixels; when none is that large
         // keep the largest one, the first in raster order among equals
         for (int r = t; r < nruns; r += FX_BLOCK) {
@@ -575,6 +788,7 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_mask_kernel(SilArgs A)
         }
         __syncthreads();
 
+        SIL_TICK(12);
         // ---- centred paste on the res x res canvas
         const int px0 = (res - new_w) / 2, py0 = (res - new_h) / 2;
         uint8_t *out = A.mask + b * (int64_t)res * res;
@@ -584,14 +798,16 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_mask_kernel(SilArgs A)
                 const int Y = ci / cpr, X0 = (ci - Y * cpr) * 16;
                 const int y = Y - py0;
                 uint32_t o[4] = {0u, 0u, 0u, 0u};
-                if (y >= 0 && y < new_h) {
+                const int x = X0 - px0;  // mask column of the chunk's first pixel
+                if (y >= 0 && y < new_h && x > -16 && x < new_w) {
                     const uint32_t *r = mA + y * wpr;
+                    const int w0 = x >> 5;  // floor, also for negative x
+                    const uint32_t lo = w0 >= 0 && w0 < wcS ? r[w0] : 0u;
+                    const uint32_t hi = w0 + 1 >= 0 && w0 + 1 < wcS ? r[w0 + 1] : 0u;
+                    const uint32_t bits = (uint32_t)(((((u64)hi) << 32) | lo) >> (x & 31)) & 0xFFFFu;
 #pragma unroll
-                    for (int k = 0; k < 16; k++) {
-                        const int x = X0 + k - px0;
-                        if (x >= 0 && x < new_w && ((r[x >> 5] >> (x & 31)) & 1u))
-                            o[k >> 2] |= 255u << (8 * (k & 3));
-                    }
+                    for (int q = 0; q < 4; q++)
+                        o[q] = sil_spread4((bits >> (4 * q)) & 0xFu);
                 }
                 *(uint4 *)(out + (int64_t)Y * res + X0) = make_uint4(o[0], o[1], o[2], o[3]);
             }
@@ -605,6 +821,15 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_mask_kernel(SilArgs A)
                 out[pi] = v;
             }
         }
+        SIL_TICK(13);
+#ifdef SIL_TIMING
+        if (t == 0 && blockIdx.x == 0 && b == 0) {
+            printf("sil ticks:");
+            for (int i = 1; i <= 13; i++)
+                printf(" %d:%llu", i, s_tick[i] - s_tick[i - 1]);
+            printf(" total %llu\n", s_tick[13] - s_tick[0]);
+        }
+#endif
         if (A.info && t == 0) {
             int32_t *f = A.info + b * 8;
             f[0] = (int32_t)thresh;
@@ -681,7 +906,23 @@ extern "C" int fx_silhouette_batch_u8(const uint8_t *d_img, int64_t B, int H, in
 
     const bool aligned = (W % 16 == 0) && (pitch % 16 == 0) && (stride % 16 == 0) && (((uintptr_t)d_img) % 16 == 0);
     const int Wp = (W + 15) & ~15;
-    const size_t blur_lds = (size_t)SIL_TROWS * Wp + 256 * sizeof(uint32_t);
+    // tile height: fewest rounds of 256 (row, 16-pixel chunk) items over the view
+    int tr = 16;
+    {
+        const int cpr = Wp / 16;
+        long best = -1;
+        for (int cand = 16; cand <= SIL_MAX_TROWS - 2 * SIL_HALO; cand++) {
+            const long tiles = (H + cand - 1) / cand;
+            const long rounds = ((long)(cand + 2 * SIL_HALO) * cpr + FX_BLOCK - 1) / FX_BLOCK;
+            const long cost = tiles * rounds * 1000 + tiles * (cand + 2 * SIL_HALO);
+            if (best < 0 || cost < best) {
+                best = cost;
+                tr = cand;
+            }
+        }
+    }
+    A.tr = tr;
+    const size_t blur_lds = (size_t)(tr + 2 * SIL_HALO) * Wp + 256 * sizeof(uint32_t);
     const size_t mask_lds = (size_t)3 * rows * wpr * sizeof(uint32_t);
     static bool attr_set = false;
     if (!attr_set) {
@@ -698,7 +939,7 @@ extern "C" int fx_silhouette_batch_u8(const uint8_t *d_img, int64_t B, int H, in
         A.mask = d_mask + b0 * (int64_t)resolution * resolution;
         A.info = d_info ? d_info + b0 * 8 : nullptr;
         FX_HIP_CHECK(hipMemsetAsync(A.hist, 0, (size_t)nb * 256 * sizeof(uint32_t), stream));
-        const dim3 bgrid((unsigned)((H + SIL_TR - 1) / SIL_TR), (unsigned)nb);
+        const dim3 bgrid((unsigned)((H + tr - 1) / tr), (unsigned)nb);
         if (aligned)
             hipLaunchKernelGGL(sil_blur_kernel<true>, bgrid, dim3(FX_BLOCK), blur_lds, stream, A);
         else

@@ -29,12 +29,39 @@ def time_pca(B, N, reps=8):
     ms.sort(); med = ms[len(ms)//2]
     return med, B*N*12/med/1e6
 
+def gray_views(B, H, W, seed=42):
+    """Rendered-view look-alikes: dark synthetic shapes on a light background + noise."""
+    shapes = eng.synth_shapes(B, H, W, seed=seed, device=dev)
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    out = torch.empty_like(shapes)
+    step = max(1, (1 << 28) // (H * W))
+    for i in range(0, B, step):
+        s = shapes[i:i + step].to(torch.float32)
+        v = 235.0 - s * (195.0 / 255.0) + torch.randn(s.shape, generator=g, device=dev) * 8.0
+        out[i:i + step] = v.clamp_(0, 255).round_().to(torch.uint8)
+    return out
+
+def time_sil(B, H, W, res, reps=5):
+    imgs = gray_views(B, H, W)
+    for _ in range(2): eng.silhouette_batch(imgs, res, 0.05, True)
+    torch.cuda.synchronize()
+    eng.profile(True); ms = []
+    for _ in range(reps):
+        eng.silhouette_batch(imgs, res, 0.05, True); ms.append(eng.profile_last_ms())
+    eng.profile(False)
+    ms.sort(); med = ms[len(ms)//2]
+    return med, B*H*W/med/1e6
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "hu"
     if what == "hu":
         for (B,H,W,c) in [(30000,512,512,False),(30000,512,512,True),(100000,256,256,False),(100000,256,256,True)]:
             ms, gbps = time_hu(B,H,W,c)
             print(f"hu B={B} {H}x{W} contour={c} dbg={os.environ.get('FX_DBG','0')}: {ms:.3f} ms  {gbps:.0f} GB/s", flush=True)
+    elif what == "sil":
+        for (B,H,W,res) in [(20000,224,224,224),(100000,224,224,224),(20000,512,512,224)]:
+            ms, gbps = time_sil(B,H,W,res)
+            print(f"sil B={B} {H}x{W}->{res}: {ms:.3f} ms  {gbps:.0f} GB/s  {B/ms/1e3:.2f} M views/s", flush=True)
     else:
         for (B,N) in [(300000,1024),(100000,2048),(1000000,256)]:
             ms, gbps = time_pca(B,N)
