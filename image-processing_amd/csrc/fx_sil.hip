@@ -59,19 +59,30 @@ __device__ __forceinline__ uint32_t sil_tap(uint32_t l, uint32_t c, uint32_t r)
 }
 
 // The three passes along a row on 22 pixels held in registers (16 + 3 on each
-// side, v[k] is pixel x0 - 3 + k).  EDGE: the row's first or last pixel is
-// among them; the neighbour of an edge pixel is the pixel itself.
-template <bool EDGE>
+// side, v[k] is pixel x0 - 3 + k).  The neighbour of the row's first or last
+// pixel is the pixel itself.  WHOLE: the row is a whole number of 16-pixel
+// chunks, so its first pixel can only be v[3] and its last only v[18]; every
+// lane runs the same code, the edge lanes differ by two selects per pass.
+template <bool WHOLE>
 __device__ __forceinline__ void sil_row_passes(uint32_t (&v)[22], int x0, int W)
 {
+    const bool first = x0 == 0, last = x0 + 16 == W;
 #pragma unroll
     for (int p = 0; p < 3; p++) {
         uint32_t n[22];
 #pragma unroll
         for (int k = 1 + p; k <= 20 - p; k++) {
-            const int x = x0 - 3 + k;
-            const uint32_t l = EDGE && x - 1 < 0 ? v[k] : v[k - 1];
-            const uint32_t r = EDGE && x + 1 > W - 1 ? v[k] : v[k + 1];
+            uint32_t l = v[k - 1], r = v[k + 1];
+            if (WHOLE) {
+                if (k == 3)
+                    l = first ? v[k] : l;
+                if (k == 18)
+                    r = last ? v[k] : r;
+            } else {
+                const int x = x0 - 3 + k;
+                l = x - 1 < 0 ? v[k] : l;
+                r = x + 1 > W - 1 ? v[k] : r;
+            }
             n[k] = sil_tap(l, v[k], r);
         }
 #pragma unroll
@@ -127,10 +138,7 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_blur_kernel(SilArgs A)
                 v[k] = row[x];
             }
         }
-        if (x0 >= 3 && x0 + 18 <= A.W - 1)
-            sil_row_passes<false>(v, x0, A.W);
-        else
-            sil_row_passes<true>(v, x0, A.W);
+        sil_row_passes<ALIGNED>(v, x0, A.W);
         uint4 o;
         o.x = v[3] | (v[4] << 8) | (v[5] << 16) | (v[6] << 24);
         o.y = v[7] | (v[8] << 8) | (v[9] << 16) | (v[10] << 24);
@@ -147,13 +155,26 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_blur_kernel(SilArgs A)
     uint8_t *dst = A.blur + b * (int64_t)A.H * A.W;
     const int olo = ilo > SIL_HALO ? ilo : SIL_HALO;                        // rows this tile writes
     const int ohi = ihi < trows - 1 - SIL_HALO ? ihi : trows - 1 - SIL_HALO;
+    // steady state: every row a step touches exists and its output row is the tile's own
+    const int f0 = (ilo + 3 > olo + 2 ? ilo + 3 : olo + 2), f1 = (ihi - 2 < ohi + 2 ? ihi - 2 : ohi + 2);
     for (int x = threadIdx.x; x < A.W; x += FX_BLOCK) {
         const uint8_t *col = tile + x;
+        uint8_t *out = dst + (int64_t)(r0 - SIL_HALO) * A.W + x;
         uint32_t c0 = 0, c1 = col[ilo * Wp], c2 = ilo + 1 <= ihi ? col[(ilo + 1) * Wp] : c1;  // input rows i-1, i, i+1
         uint32_t p1a = 0, p1b = 0, p1c = 0;   // pass 1 at rows i-2, i-1, i
         uint32_t p2a = 0, p2b = 0, p2c = 0;   // pass 2 at rows i-3, i-2, i-1
         uint32_t run_v = 0, run_n = 0;
-        for (int i = ilo; i <= ihi + 2; i++) {
+        // neighbouring rows mostly share a value: one LDS atomic per stretch
+        auto emit = [&](int row, uint32_t v) {
+            out[(int64_t)row * A.W] = (uint8_t)v;
+            if (v != run_v && run_n) {
+                atomicAdd(&hist[run_v], run_n);
+                run_n = 0;
+            }
+            run_v = v;
+            run_n++;
+        };
+        auto edge_step = [&](int i) {
             const uint32_t c3 = i + 2 <= ihi ? col[(i + 2) * Wp] : 0u;  // prefetch of row i + 2
             if (i <= ihi) {
                 const uint32_t up = i - 1 < ilo ? c1 : c0, dn = i + 1 > ihi ? c1 : c2;
@@ -175,20 +196,31 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_blur_kernel(SilArgs A)
                 const uint32_t mid = i - 1 <= ihi ? p2b : p2c;
                 const uint32_t above = i - 1 <= ihi ? p2a : p2b;
                 const uint32_t up = i - 3 < ilo ? mid : above, dn = i - 1 > ihi ? mid : p2c;
-                const uint32_t v = sil_tap(up, mid, dn);
-                dst[(int64_t)(r0 - SIL_HALO + i - 2) * A.W + x] = (uint8_t)v;
-                // neighbouring rows mostly share a value: one LDS atomic per stretch
-                if (v != run_v && run_n) {
-                    atomicAdd(&hist[run_v], run_n);
-                    run_n = 0;
-                }
-                run_v = v;
-                run_n++;
+                emit(i - 2, sil_tap(up, mid, dn));
             }
             c0 = c1;
             c1 = c2;
             c2 = c3;
+        };
+        int i = ilo;
+        for (; i <= ihi + 2 && i < f0; i++)
+            edge_step(i);
+#pragma unroll 6
+        for (; i <= f1; i++) {
+            const uint32_t c3 = col[(i + 2) * Wp];
+            p1a = p1b;
+            p1b = p1c;
+            p1c = sil_tap(c0, c1, c2);
+            p2a = p2b;
+            p2b = p2c;
+            p2c = sil_tap(p1a, p1b, p1c);
+            emit(i - 2, sil_tap(p2a, p2b, p2c));
+            c0 = c1;
+            c1 = c2;
+            c2 = c3;
         }
+        for (; i <= ihi + 2; i++)
+            edge_step(i);
         if (run_n)
             atomicAdd(&hist[run_v], run_n);
     }

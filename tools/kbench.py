@@ -58,6 +58,9 @@ if __name__ == "__main__":
         for (B,H,W,c) in [(30000,512,512,False),(30000,512,512,True),(100000,256,256,False),(100000,256,256,True)]:
             ms, gbps = time_hu(B,H,W,c)
             print(f"hu B={B} {H}x{W} contour={c} dbg={os.environ.get('FX_DBG','0')}: {ms:.3f} ms  {gbps:.0f} GB/s", flush=True)
+    elif what == "sil1":
+        ms, gbps = time_sil(20000, 224, 224, 224, reps=3)
+        print(f"sil B=20000 224x224->224: {ms:.3f} ms  {gbps:.0f} GB/s", flush=True)
     elif what == "sil":
         for (B,H,W,res) in [(20000,224,224,224),(100000,224,224,224),(20000,512,512,224)]:
             ms, gbps = time_sil(B,H,W,res)
