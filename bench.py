@@ -13,6 +13,9 @@ One step = one pass of the hot path over the batch that is resident in HBM:
   c2            100 000 x 256x256, Hu only.
   c4            1 000 000 point sets of 1024 x 3 float32 split over the ranks
                 (strong scaling), PCA descriptor.
+  f1            20 000 gray 224x224 views per GPU (dark synthetic shapes on a
+                light background + noise): silhouette preprocessing + Hu, the
+                stage in front of the headline path.
 
 Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events
 that libfx records on the launch stream around its own kernel; `cpu_baseline`
@@ -43,6 +46,9 @@ WORKLOADS = {
                desc="100k x 256x256 u8 shapes per GPU; Hu only"),
     "c4": dict(kind="pca", total=1_000_000, N=1024, bytes_per_unit=1024 * 3 * 4, scaling="strong",
                desc="1M point sets of 1024x3 f32 over all GPUs; PCA descriptor"),
+    "f1": dict(kind="sil+hu", per_gpu=20_000, H=224, W=224, bytes_per_unit=224 * 224, scaling="weak",
+               desc="20k gray 224x224 views per GPU; silhouette preprocessing (blur, Otsu, morphology, crop, "
+                    "resize, component filter) + Hu"),
 }
 
 
@@ -81,7 +87,8 @@ def cpu_baseline(kind: str, sample, cores: int) -> dict:
     units = sum(d[0] for d in done)
     return {"value": units / wall, "unit": "images/s" if kind != "pca" else "sets/s", "cores": len(jobs), "kind": "port",
             "sample": f"{units} units of the benchmark's own synthetic data, {wall:.1f} s wall on {len(jobs)} worker processes "
-                      f"(C restatement of cv2.moments/HuMoments + NumPy cov/eigh/histogram per unit)"}
+                      f"(C restatement of cv2.moments/HuMoments + NumPy cov/eigh/histogram per unit"
+                      + ("; PIL + scipy.ndimage silhouette as in the reference" if kind == "sil+hu" else "") + ")"}
 
 
 def main():
@@ -124,13 +131,25 @@ def main():
         for a in range(0, units, chunk):  # chunked so that a launch stays short
             b = min(units, a + chunk)
             eng.synth_shapes(b - a, wl["H"], wl["W"], seed=42, first_index=lo + a, device=dev, out=data[a:b])
+            if kind == "sil+hu":  # rendered-view look-alike: dark shape, light background, sensor-like noise
+                g = torch.Generator(device=dev)
+                g.manual_seed(42 + lo + a)
+                v = 235.0 - data[a:b].to(torch.float32) * (195.0 / 255.0)
+                v += torch.randn(v.shape, generator=g, device=dev) * 8.0
+                data[a:b] = v.clamp_(0, 255).round_().to(torch.uint8)
     torch.cuda.synchronize()
+
+    sil_ms = []
 
     def step():
         if kind == "pca":
             feats = eng.pca_batch(data, None, 8, False)["out"]
         elif kind == "hu":
             feats = eng.hu_batch(data, thresh=127, on_value=255)["hulog7"]
+        elif kind == "sil+hu":
+            masks = eng.silhouette_batch(data, 224, 0.05, True)["mask"]
+            sil_ms.append(eng.profile_last_ms())   # the Hu launch below overwrites the event pair
+            feats = eng.hu_batch(masks)["hulog7"]
         else:
             r = eng.hu_batch(data, thresh=127, on_value=255, contour_bins=8)
             feats = torch.cat([r["hulog7"], r["cpca"]], dim=1)
@@ -158,7 +177,7 @@ def main():
         step()
         # reading the event pair waits for this step's kernel; the next step is
         # enqueued right after, which costs one launch latency per step
-        kernel_ms.append(eng.profile_last_ms())
+        kernel_ms.append(sil_ms[-1] if kind == "sil+hu" else eng.profile_last_ms())
     fence()
     elapsed = time.perf_counter() - t0
     eng.profile(False)
@@ -184,19 +203,20 @@ def main():
             "value": total * args.steps / elapsed, "unit": unit, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": wl["scaling"], "vs_baseline": None,
-            "dtype": "f64" if kind == "pca" else "int64",
+            "dtype": "f64" if kind == "pca" else ("u32" if kind == "sil+hu" else "int64"),
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {wl['desc']}", "units_per_gpu": units, "total_units": total,
                        "parallelism": f"dp{world} (units sharded, all-gather of features)" if world > 1 else "single GPU",
                        "bytes_per_unit": wl["bytes_per_unit"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": {"pca": "pca_sets_reg_kernel", "hu": "hu_band_kernel", "hu+cpca": "hu_band_kernel"}[kind],
+                         "kernel": {"pca": "pca_sets_reg_kernel", "hu": "hu_band_kernel", "hu+cpca": "hu_band_kernel",
+                                    "sil+hu": "sil_mask_kernel"}[kind],
                          "kernel_ms": kavg, "units_per_launch": units},
         }
         if world == 1 and not args.no_cpu_baseline:
             cores = min(16, os.cpu_count() or 1)
-            n_s = args.cpu_sample or (cores * (12000 if kind == "pca" else (2400 if kind == "hu+cpca" else 12000)))
+            n_s = args.cpu_sample or (cores * {"pca": 12000, "hu+cpca": 2400, "hu": 12000, "sil+hu": 400}[kind])
             n_s = min(n_s, units)
             sample = data[:n_s].cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(kind, sample, cores)

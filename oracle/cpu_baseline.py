@@ -31,6 +31,10 @@ def run(job):
     elif kind == "hu":
         for img in data:
             c.hu_batch(img[None], thresh=127, on_value=255)
+    elif kind == "sil+hu":
+        for img in data:
+            mask, _ = cpu_ref.silhouette(img, 224, 0.05, True)
+            c.hu_batch(mask[None])
     else:
         for img in data:
             c.hu_batch(img[None], thresh=127, on_value=255)
