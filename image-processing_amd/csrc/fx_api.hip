@@ -7,13 +7,13 @@
 namespace {
 
 constexpr int kMaxDevices = 16;
-constexpr int kScratchSlots = 4;
+constexpr int kScratchSlots = 6;
 
 thread_local char g_err[512] = "";
 
 struct DeviceState {
-    void *scratch[kScratchSlots] = {nullptr, nullptr, nullptr, nullptr};
-    size_t scratch_bytes[kScratchSlots] = {0, 0, 0, 0};
+    void *scratch[kScratchSlots] = {};
+    size_t scratch_bytes[kScratchSlots] = {};
 };
 
 std::mutex g_mu;

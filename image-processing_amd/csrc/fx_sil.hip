@@ -985,3 +985,201 @@ extern "C" int fx_silhouette_batch_u8(const uint8_t *d_img, int64_t B, int H, in
     }
     return FX_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Gray half of preprocess_image: pad_and_resize (reference :224-240) =
+// PIL ImageOps.contain (bicubic) of the cropped view + centred paste on the
+// background colour.  PIL's 8-bit resampler is restated: float64 bicubic
+// weights over a support of 2 * max(scale, 1) source pixels, normalised, turned
+// into 22-bit fixed point with rounding, a pass along x into a uint8 image,
+// then a pass along y, each (2^21 + sum(pixel * k)) >> 22 clamped to 0..255.
+// ---------------------------------------------------------------------------
+namespace {
+
+constexpr int FIT_PRECISION_BITS = 32 - 8 - 2;
+constexpr int FIT_MAX_COEFFS = 4 * SIL_MAX_SIDE + 5 * SIL_MAX_SIDE;  // outSize * ksize never exceeds this
+
+struct FitArgs {
+    const uint8_t *img;
+    int64_t B;
+    int H, W;
+    int64_t pitch, stride;
+    const int32_t *info;  // [B][8] as written by the silhouette call (columns 2..5 = crop), or null
+    int res;
+    int bg;
+    uint8_t *out;   // [B][res][res]
+    uint8_t *temp;  // [grid][SIL_MAX_SIDE * SIL_MAX_SIDE]
+};
+
+__device__ __forceinline__ double fit_bicubic(double x)
+{
+    if (x < 0.0)
+        x = -x;
+    if (x < 1.0)
+        return (1.5 * x - 2.5) * x * x + 1;
+    if (x < 2.0)
+        return (((x - 5) * x + 8) * x - 4) * -0.5;
+    return 0.0;
+}
+
+// Coefficients of one axis: k[xx * ksize + j] (fixed point), lo[xx], cnt[xx].
+__device__ void fit_coeffs(int in_size, int out_size, int ksize, double scale, double filterscale, int32_t *k,
+                           uint16_t *lo, uint16_t *cnt)
+{
+    const double support = 2.0 * filterscale;
+    const double ss = 1.0 / filterscale;
+    for (int xx = threadIdx.x; xx < out_size; xx += FX_BLOCK) {
+        const double center = 0.0 + ((double)xx + 0.5) * scale;
+        int xmin = (int)(center - support + 0.5);
+        xmin = xmin < 0 ? 0 : xmin;
+        int xmax = (int)(center + support + 0.5);
+        xmax = xmax > in_size ? in_size : xmax;
+        xmax -= xmin;
+        int32_t *kk = k + xx * ksize;
+        double ww = 0.0;
+        for (int x = 0; x < xmax; x++)
+            ww += fit_bicubic(((double)(x + xmin) - center + 0.5) * ss);
+        for (int x = 0; x < xmax; x++) {
+            double w = fit_bicubic(((double)(x + xmin) - center + 0.5) * ss);
+            if (ww != 0.0)
+                w /= ww;
+            kk[x] = w < 0 ? (int)(-0.5 + w * (double)(1 << FIT_PRECISION_BITS))
+                          : (int)(0.5 + w * (double)(1 << FIT_PRECISION_BITS));
+        }
+        lo[xx] = (uint16_t)xmin;
+        cnt[xx] = (uint16_t)xmax;
+    }
+}
+
+__device__ __forceinline__ uint8_t fit_clip8(int v)
+{
+    v >>= FIT_PRECISION_BITS;
+    return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+__global__ __launch_bounds__(FX_BLOCK) void gray_fit_kernel(FitArgs A)
+{
+    __shared__ int32_t s_kx[FIT_MAX_COEFFS], s_ky[FIT_MAX_COEFFS];
+    __shared__ uint16_t s_xlo[SIL_MAX_SIDE], s_xcnt[SIL_MAX_SIDE], s_ylo[SIL_MAX_SIDE], s_ycnt[SIL_MAX_SIDE];
+    const int t = threadIdx.x, res = A.res;
+    uint8_t *temp = A.temp + (int64_t)blockIdx.x * SIL_MAX_SIDE * SIL_MAX_SIDE;
+
+    for (int64_t b = blockIdx.x; b < A.B; b += gridDim.x) {
+        __syncthreads();
+        int x0 = 0, y0 = 0, x1 = A.W, y1 = A.H;
+        if (A.info) {
+            const int32_t *f = A.info + b * 8;
+            x0 = f[2];
+            y0 = f[3];
+            x1 = f[4];
+            y1 = f[5];
+        }
+        const int cw = x1 - x0, ch = y1 - y0;
+        // ImageOps.contain: the longer side becomes res, the other round(ratio * res) (half to even)
+        int nw = res, nh = res;
+        {
+            const double im_ratio = (double)cw / (double)ch;
+            if (im_ratio != 1.0) {
+                if (im_ratio > 1.0)
+                    nh = (int)rint((double)ch / (double)cw * (double)res);
+                else
+                    nw = (int)rint((double)cw / (double)ch * (double)res);
+            }
+            nw = nw < 1 ? 1 : nw;
+            nh = nh < 1 ? 1 : nh;
+        }
+        const bool horiz = nw != cw, vert = nh != ch;
+        const double sx = (double)((float)cw - 0.0f) / (double)nw, sy = (double)((float)ch - 0.0f) / (double)nh;
+        const double fsx = sx < 1.0 ? 1.0 : sx, fsy = sy < 1.0 ? 1.0 : sy;
+        const int kxs = (int)ceil(2.0 * fsx) * 2 + 1, kys = (int)ceil(2.0 * fsy) * 2 + 1;
+        if (horiz)
+            fit_coeffs(cw, nw, kxs, sx, fsx, s_kx, s_xlo, s_xcnt);
+        if (vert)
+            fit_coeffs(ch, nh, kys, sy, fsy, s_ky, s_ylo, s_ycnt);
+        __syncthreads();
+
+        const uint8_t *src = A.img + b * A.stride + (int64_t)y0 * A.pitch + x0;
+        // pass along x: temp[y][xx], ch rows of nw pixels
+        if (horiz) {
+            for (int i = t; i < ch * nw; i += FX_BLOCK) {
+                const int y = i / nw, xx = i - y * nw;
+                const uint8_t *p = src + (int64_t)y * A.pitch + s_xlo[xx];
+                const int32_t *k = s_kx + xx * kxs;
+                const int n = s_xcnt[xx];
+                int acc = 1 << (FIT_PRECISION_BITS - 1);
+                for (int j = 0; j < n; j++)
+                    acc += __mul24((int)p[j], k[j]);
+                temp[i] = fit_clip8(acc);
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+        // pass along y and paste
+        const int px0 = (res - nw) / 2, py0 = (res - nh) / 2;
+        uint8_t *out = A.out + b * (int64_t)res * res;
+        for (int i = t; i < res * res; i += FX_BLOCK) {
+            const int Y = i / res, X = i - Y * res;
+            const int yy = Y - py0, xx = X - px0;
+            int v = A.bg;
+            if (yy >= 0 && yy < nh && xx >= 0 && xx < nw) {
+                if (vert) {
+                    const int32_t *k = s_ky + yy * kys;
+                    const int n = s_ycnt[yy], lo = s_ylo[yy];
+                    int acc = 1 << (FIT_PRECISION_BITS - 1);
+                    if (horiz) {
+                        for (int j = 0; j < n; j++)
+                            acc += __mul24((int)((volatile uint8_t *)temp)[(lo + j) * nw + xx], k[j]);
+                    } else {
+                        for (int j = 0; j < n; j++)
+                            acc += __mul24((int)src[(int64_t)(lo + j) * A.pitch + xx], k[j]);
+                    }
+                    v = fit_clip8(acc);
+                } else {
+                    v = horiz ? ((volatile uint8_t *)temp)[yy * nw + xx] : src[(int64_t)yy * A.pitch + xx];
+                }
+            }
+            out[i] = (uint8_t)v;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int fx_gray_fit_batch_u8(const uint8_t *d_img, int64_t B, int H, int W, int64_t pitch, int64_t stride,
+                                    const int32_t *d_info, int resolution, int bg_value, uint8_t *d_out,
+                                    void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    FX_REQUIRE(B >= 0, "fx_gray_fit_batch_u8: B = %lld", (long long)B);
+    if (B == 0)
+        return FX_OK;
+    FX_REQUIRE(d_img && d_out, "fx_gray_fit_batch_u8: null image or output pointer");
+    FX_REQUIRE(H >= 1 && W >= 1 && H <= SIL_MAX_SIDE && W <= SIL_MAX_SIDE,
+               "fx_gray_fit_batch_u8: views of %dx%d; supported up to %dx%d", H, W, SIL_MAX_SIDE, SIL_MAX_SIDE);
+    FX_REQUIRE(resolution >= 1 && resolution <= SIL_MAX_SIDE, "fx_gray_fit_batch_u8: resolution %d outside 1..%d",
+               resolution, SIL_MAX_SIDE);
+    FX_REQUIRE(pitch >= W && (B == 1 || stride >= (int64_t)(H - 1) * pitch + W),
+               "fx_gray_fit_batch_u8: pitch %lld / stride %lld too small for %dx%d", (long long)pitch,
+               (long long)stride, H, W);
+    FX_REQUIRE(bg_value >= 0 && bg_value <= 255, "fx_gray_fit_batch_u8: bg_value %d", bg_value);
+    const int grid = (int)(B < 1024 ? B : 1024);
+    uint8_t *temp = (uint8_t *)fx_scratch((size_t)grid * SIL_MAX_SIDE * SIL_MAX_SIDE, 4);
+    if (!temp)
+        return FX_ENOMEM;
+    FitArgs A;
+    A.img = d_img;
+    A.B = B;
+    A.H = H;
+    A.W = W;
+    A.pitch = pitch;
+    A.stride = stride;
+    A.info = d_info;
+    A.res = resolution;
+    A.bg = bg_value;
+    A.out = d_out;
+    A.temp = temp;
+    FxProfileScope prof(stream);
+    hipLaunchKernelGGL(gray_fit_kernel, dim3(grid), dim3(FX_BLOCK), 0, stream, A);
+    FX_HIP_CHECK(hipGetLastError());
+    return FX_OK;
+}

@@ -102,6 +102,33 @@ def silhouette_batch(images: torch.Tensor, resolution: int = 224, crop_margin: f
     return out
 
 
+def gray_fit_batch(images: torch.Tensor, info: Optional[torch.Tensor] = None, resolution: int = 224,
+                   bg_value: int = 255) -> torch.Tensor:
+    """Bicubic aspect-preserving fit of each view's crop rectangle (columns 2..5
+    of the silhouette call's info block, or the whole view) into a
+    resolution x resolution canvas of bg_value: uint8 [B, resolution, resolution]."""
+    _require_cuda(images, "images")
+    if images.dtype != torch.uint8 or images.dim() != 3:
+        raise ValueError(f"images must be uint8 [B, H, W], got {images.dtype} {tuple(images.shape)}")
+    if images.stride(2) != 1 and images.shape[2] > 1:
+        raise ValueError("images must have a unit stride along the row")
+    B, H, W = images.shape
+    if info is not None:
+        _require_cuda(info, "info")
+        if info.dtype != torch.int32 or tuple(info.shape) != (B, 8) or not info.is_contiguous():
+            raise ValueError("info must be contiguous int32 [B, 8]")
+    stream = _enter(images.device)
+    res = int(resolution)
+    out = torch.empty((B, res, res), dtype=torch.uint8, device=images.device)
+    if B == 0:
+        return out
+    pitch = images.stride(1) if H > 1 else W
+    stride = images.stride(0) if B > 1 else pitch * H
+    _lib.call("fx_gray_fit_batch_u8", images.data_ptr(), B, H, W, pitch, stride, _ptr(info), res, int(bg_value),
+              out.data_ptr(), stream)
+    return out
+
+
 def hu_groupstat(hulog7: torch.Tensor, group_offsets: torch.Tensor) -> torch.Tensor:
     """mean || std (ddof=0, float32) of the rows of each group -> f32 [G, 14]."""
     _require_cuda(hulog7, "hulog7")

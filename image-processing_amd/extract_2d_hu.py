@@ -10,9 +10,8 @@ The silhouette preprocessing in front of it (:101-440: blur, Otsu, morphology,
 bounding-box crop, nearest resize, mask cleaning) runs on the device as well
 (csrc/fx_sil.hip) and follows the code path the reference itself takes when
 OpenCV is not installed (PIL + scipy.ndimage), which is the only one of its two
-paths that can be run and checked in an environment without cv2.  Image
-decoding, and the bicubic fit of the gray image that is only needed without
---use_silhouette, are PIL calls on the host.
+paths that can be run and checked in an environment without cv2.  Only the
+image decoding is a PIL call on the host.
 
 Added next to the reference API: `compute_hu_batch` and `process_samples`,
 which push many views through one kernel launch.
@@ -27,7 +26,7 @@ from pathlib import Path
 from typing import Any, Dict, Iterable, List, Optional, Sequence, Tuple
 
 import numpy as np
-from PIL import Image, ImageOps
+from PIL import Image
 
 logger = logging.getLogger("extract_2d_hu")
 
@@ -70,14 +69,16 @@ def _device():
 
 
 def pad_and_resize(img: np.ndarray, target: int, bg_color: str) -> np.ndarray:
-    """Aspect-preserving fit of the gray image into target x target, centred on
-    the background colour (reference :224-240).  Host code (PIL bicubic): only
-    needed when the moments are taken from the gray image instead of the
-    silhouette."""
-    fitted = ImageOps.contain(Image.fromarray(img), (target, target)).convert("L")
-    canvas = Image.new("L", (target, target), color=255 if bg_color == "white" else 0)
-    canvas.paste(fitted, ((target - fitted.width) // 2, (target - fitted.height) // 2))
-    return np.asarray(canvas, dtype=np.uint8)
+    """Aspect-preserving bicubic fit of the gray image into target x target,
+    centred on the background colour (reference :224-240, PIL
+    ImageOps.contain + paste), computed on the device."""
+    import torch
+    from . import engine
+
+    arr = np.ascontiguousarray(img, dtype=np.uint8)
+    out = engine.gray_fit_batch(torch.from_numpy(arr[None]).to(_device()), None, target,
+                                255 if bg_color == "white" else 0)
+    return out[0].cpu().numpy()
 
 
 def compute_silhouettes(images: np.ndarray, resolution: int, crop_margin: float, preprocess_crop: bool):
@@ -100,12 +101,15 @@ def compute_silhouettes(images: np.ndarray, resolution: int, crop_margin: float,
 def preprocess_image(img: np.ndarray, resolution: int, crop_margin: float, bg_color: str,
                      preprocess_crop: bool) -> Tuple[np.ndarray, np.ndarray]:
     """(preprocessed gray image, cleaned 0/255 silhouette), both
-    resolution x resolution uint8 (reference :352-440).  The silhouette and the
-    crop rectangle come from the device; the gray fit is PIL on the host."""
+    resolution x resolution uint8 (reference :352-440), both from the device."""
+    import torch
+    from . import engine
+
     assert img.ndim == 2
-    masks, info = compute_silhouettes(img, resolution, crop_margin, preprocess_crop)
-    x0, y0, x1, y1 = (int(v) for v in info[0, 2:6])
-    return pad_and_resize(img[y0:y1, x0:x1], resolution, bg_color), masks[0]
+    d = torch.from_numpy(np.ascontiguousarray(img, dtype=np.uint8)[None]).to(_device())
+    sil = engine.silhouette_batch(d, resolution, crop_margin, preprocess_crop, info=True)
+    pre = engine.gray_fit_batch(d, sil["info"], resolution, 255 if bg_color == "white" else 0)
+    return pre[0].cpu().numpy(), sil["mask"][0].cpu().numpy()
 
 
 def compute_hu_batch(images: Sequence[np.ndarray] | np.ndarray, thresh: int = -1, on_value: int = 255,
@@ -225,10 +229,7 @@ def process_samples(tasks: Iterable[Tuple[str, str, Dict[str, Any]]]) -> List[Di
             if use_silhouette:
                 target = sil["mask"]
             else:
-                info = sil["info"].cpu().numpy()
-                target = torch.from_numpy(np.stack([
-                    pad_and_resize(views[i][r[3]:r[5], r[2]:r[4]], resolution, bg_color)
-                    for i, r in zip(idx, info)])).to(dev)
+                target = engine.gray_fit_batch(raw, sil["info"], resolution, 255 if bg_color == "white" else 0)
             off = np.zeros(len(counts) + 1, dtype=np.int64)
             np.cumsum(counts, out=off[1:])
             rows = engine.hu_batch(target)["hulog7"]

@@ -152,6 +152,21 @@ int fx_silhouette_batch_u8(const uint8_t *d_img, int64_t B, int H, int W,
                            uint8_t *d_mask, int32_t *d_info, void *stream);
 
 /*
+ * Gray half of preprocess_image: pad_and_resize, src/features/extract_2d_hu.py
+ * :224-240 (PIL ImageOps.contain with its default bicubic filter, then a
+ * centred paste on a canvas of the background colour), applied to the crop
+ * rectangle of each view.  d_info is the int32 [B, 8] block written by
+ * fx_silhouette_batch_u8 (columns 2..5 = x0, y0, x1, y1) or NULL for the whole
+ * view.  Bit-identical to PIL's 8-bit resampler (float64 weights, 22-bit fixed
+ * point, a pass along x, then along y).  bg_value: 255 for "white", 0 for
+ * "black".  d_out uint8 [B, resolution, resolution].  Views and resolution up
+ * to 512 x 512.
+ */
+int fx_gray_fit_batch_u8(const uint8_t *d_img, int64_t B, int H, int W,
+                         int64_t pitch, int64_t stride, const int32_t *d_info,
+                         int resolution, int bg_value, uint8_t *d_out, void *stream);
+
+/*
  * Synthetic inputs for benchmarks and parity tests (no reference counterpart:
  * the reference reads rendered PNG views and sampled .npy clouds from disk).
  * Image `first_index + b` / set `first_index + b` depends only on (seed, that

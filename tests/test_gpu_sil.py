@@ -136,3 +136,55 @@ def test_large_batch_is_deterministic_and_chunked(gpu, oracle):
     for k in range(8):
         np.testing.assert_array_equal(first[k], oracle.silhouette(base[k], 224, 0.05, True)[0])
     assert torch.equal(out.view(reps, 8, 224, 224), out[:8].unsqueeze(0).expand(reps, -1, -1, -1))
+
+
+# ------------------------------------------------------------ gray fit (pad_and_resize)
+def fit(gpu, imgs, info, res, bg):
+    eng = pkg("engine")
+    d_info = None if info is None else torch.from_numpy(np.ascontiguousarray(info, dtype=np.int32)).to(gpu)
+    out = eng.gray_fit_batch(torch.from_numpy(np.ascontiguousarray(imgs)).to(gpu), d_info, res, bg)
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def test_gray_fit_golden_of_the_reference(gpu):
+    g = np.load(GOLDEN / "preprocess_golden.npz")
+    imgs = g["inputs"]
+    for crop, tag in ((False, "nocrop"), (True, "crop")):
+        _, info = run(gpu, imgs, 224, 0.05, crop)
+        np.testing.assert_array_equal(fit(gpu, imgs, info, 224, 255), g[f"preproc_{tag}"])
+
+
+@pytest.mark.parametrize("h,w,res", [(224, 224, 224), (224, 224, 128), (97, 131, 100), (131, 97, 300), (512, 512, 224),
+                                     (512, 300, 512), (40, 500, 64), (17, 9, 224), (1, 1, 8), (3, 200, 64)])
+def test_gray_fit_equals_pil(gpu, oracle, h, w, res):
+    rng = np.random.default_rng(h * 977 + w)
+    imgs = np.stack([rng.integers(0, 256, (h, w), dtype=np.uint8), gray_scene(rng, h, w),
+                     np.full((h, w), 255, dtype=np.uint8), (np.indices((h, w)).sum(0) % 2 * 255).astype(np.uint8)])
+    for bg, name in ((255, "white"), (0, "black")):
+        got = fit(gpu, imgs, None, res, bg)
+        for k in range(len(imgs)):
+            np.testing.assert_array_equal(got[k], oracle.pad_and_resize(imgs[k], res, name), err_msg=f"image {k}")
+    # crop rectangles of every shape, including single rows and columns
+    info = np.zeros((len(imgs), 8), dtype=np.int32)
+    rects = [(0, 0, w, h), (w // 3, h // 4, w, h), (0, 0, max(1, w // 2), max(1, h // 3)), (w - 1, 0, w, h)]
+    for k, (x0, y0, x1, y1) in enumerate(rects):
+        info[k, 2:6] = (x0, y0, x1, y1)
+    got = fit(gpu, imgs, info, res, 255)
+    for k, (x0, y0, x1, y1) in enumerate(rects):
+        if (y1 - y0) / (x1 - x0) * res < 0.5 or (x1 - x0) / (y1 - y0) * res < 0.5:
+            continue   # PIL refuses a zero-sized target; the device clamps it to one pixel
+        np.testing.assert_array_equal(got[k], oracle.pad_and_resize(imgs[k][y0:y1, x0:x1], res, "white"),
+                                      err_msg=f"rect {k}")
+
+
+def test_preprocess_image_signature(gpu, oracle, hu_panels):
+    hu = pkg("extract_2d_hu")
+    img = hu_panels["raw_views"][3, 1]
+    for crop in (False, True):
+        pre, mask = hu.preprocess_image(img, 224, 0.05, "white", crop)
+        wpre, wmask = oracle.preprocess_image(img, 224, 0.05, "white", crop)
+        np.testing.assert_array_equal(pre, wpre)
+        np.testing.assert_array_equal(mask, wmask)
+    np.testing.assert_array_equal(hu.pad_and_resize(img[10:200, 30:180], 96, "black"),
+                                  oracle.pad_and_resize(img[10:200, 30:180], 96, "black"))
