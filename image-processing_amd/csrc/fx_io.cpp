@@ -1,0 +1,254 @@
+// libfx host I/O: many small files in and out on native threads.
+//
+// The reference loads one .npy cloud per pool task with np.load
+// (src/features/extract_3d_pca_features.py:48-56) and writes one descriptor per
+// cloud with np.save (:148-158).  In Python that is ~150 us of interpreter time
+// per file, which no thread pool hides; here a batch of files is read straight
+// into the caller's (page-locked) buffer and a batch of descriptors is written
+// by native threads.
+#include <atomic>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <string_view>
+#include <thread>
+#include <vector>
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include "../../include/fx.h"
+
+void fx_set_error(const char *fmt, ...);
+
+namespace {
+
+struct NpyHeader {
+    int itemsize = 0;      // 4 (<f4) or 8 (<f8)
+    int64_t rows = 0, cols = 0;
+    int64_t data_offset = 0;
+};
+
+// Parses the header of an .npy file (format 1.0 - 3.0) that holds a 2-D
+// little-endian C-order float32/float64 array.  Returns FX_IO_OK or a status.
+int parse_npy_header(const unsigned char *buf, size_t len, NpyHeader *h)
+{
+    if (len < 12 || memcmp(buf, "\x93NUMPY", 6) != 0)
+        return FX_IO_EFORMAT;
+    const int major = buf[6];
+    size_t hlen, off;
+    if (major == 1) {
+        hlen = (size_t)buf[8] | ((size_t)buf[9] << 8);
+        off = 10;
+    } else if (major == 2 || major == 3) {
+        hlen = (size_t)buf[8] | ((size_t)buf[9] << 8) | ((size_t)buf[10] << 16) | ((size_t)buf[11] << 24);
+        off = 12;
+    } else {
+        return FX_IO_EFORMAT;
+    }
+    if (off + hlen > len)
+        return FX_IO_EFORMAT;
+    const char *t = (const char *)buf + off;
+    const std::string_view text(t, hlen);
+    auto find_after = [&](const char *key) -> size_t {
+        const size_t p = text.find(key);
+        return p == std::string_view::npos ? p : p + strlen(key);
+    };
+    size_t p = find_after("'descr':");
+    if (p == std::string_view::npos)
+        return FX_IO_EFORMAT;
+    while (p < hlen && (text[p] == ' '))
+        p++;
+    if (p + 5 > hlen || (text[p] != '\'' && text[p] != '"'))
+        return FX_IO_EDTYPE;
+    const std::string_view descr = text.substr(p + 1, 3);
+    if (descr == "<f4")
+        h->itemsize = 4;
+    else if (descr == "<f8")
+        h->itemsize = 8;
+    else
+        return FX_IO_EDTYPE;
+    p = find_after("'fortran_order':");
+    if (p == std::string_view::npos)
+        return FX_IO_EFORMAT;
+    while (p < hlen && text[p] == ' ')
+        p++;
+    if (text.substr(p, 5) != "False")
+        return FX_IO_EDTYPE;
+    p = find_after("'shape':");
+    if (p == std::string_view::npos)
+        return FX_IO_EFORMAT;
+    while (p < hlen && text[p] != '(')
+        p++;
+    p++;
+    int64_t dims[3] = {0, 0, 0};
+    int nd = 0;
+    while (p < hlen && text[p] != ')') {
+        if (text[p] >= '0' && text[p] <= '9') {
+            if (nd >= 3)
+                return FX_IO_ESHAPE;
+            int64_t v = 0;
+            while (p < hlen && text[p] >= '0' && text[p] <= '9')
+                v = v * 10 + (text[p++] - '0');
+            dims[nd++] = v;
+        } else {
+            p++;
+        }
+    }
+    if (nd != 2)
+        return FX_IO_ESHAPE;
+    h->rows = dims[0];
+    h->cols = dims[1];
+    h->data_offset = (int64_t)(off + hlen);
+    return FX_IO_OK;
+}
+
+bool read_fully(int fd, void *dst, size_t n, off_t off)
+{
+    unsigned char *p = (unsigned char *)dst;
+    while (n) {
+        const ssize_t r = pread(fd, p, n, off);
+        if (r <= 0)
+            return false;
+        p += r;
+        off += r;
+        n -= (size_t)r;
+    }
+    return true;
+}
+
+int read_one_points(const char *path, int64_t want_rows, float *out, int64_t *rows_found)
+{
+    const int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0)
+        return FX_IO_EOPEN;
+    unsigned char head[4096];
+    const ssize_t got = pread(fd, head, sizeof(head), 0);
+    NpyHeader h;
+    int st = got > 0 ? parse_npy_header(head, (size_t)got, &h) : FX_IO_EFORMAT;
+    if (st == FX_IO_OK) {
+        *rows_found = h.rows;
+        if (h.cols < 3)
+            st = FX_IO_ESHAPE;
+        else if (h.rows != want_rows)
+            st = FX_IO_EROWS;
+    }
+    if (st == FX_IO_OK) {
+        if (h.itemsize == 4 && h.cols == 3) {
+            if (!read_fully(fd, out, (size_t)want_rows * 3 * sizeof(float), (off_t)h.data_offset))
+                st = FX_IO_EREAD;
+        } else {
+            const size_t bytes = (size_t)h.rows * (size_t)h.cols * (size_t)h.itemsize;
+            std::vector<unsigned char> tmp(bytes);
+            if (!read_fully(fd, tmp.data(), bytes, (off_t)h.data_offset)) {
+                st = FX_IO_EREAD;
+            } else if (h.itemsize == 4) {
+                const float *s = (const float *)tmp.data();
+                for (int64_t r = 0; r < h.rows; r++)
+                    for (int c = 0; c < 3; c++)
+                        out[r * 3 + c] = s[r * h.cols + c];
+            } else {
+                const double *s = (const double *)tmp.data();
+                for (int64_t r = 0; r < h.rows; r++)
+                    for (int c = 0; c < 3; c++)
+                        out[r * 3 + c] = (float)s[r * h.cols + c];  // round to nearest even, as astype does
+            }
+        }
+    }
+    close(fd);
+    return st;
+}
+
+int write_one_row(const char *path, const float *row, int64_t len)
+{
+    // .npy format 1.0, 1-D little-endian float32, header padded so that the
+    // data starts at a multiple of 64 bytes (what np.save writes)
+    char dict[128];
+    const int dn = snprintf(dict, sizeof(dict), "{'descr': '<f4', 'fortran_order': False, 'shape': (%lld,), }",
+                            (long long)len);
+    size_t hlen = (size_t)dn + 1;  // + '\n'
+    const size_t pad = (64 - (10 + hlen) % 64) % 64;
+    hlen += pad;
+    std::vector<unsigned char> buf(10 + hlen + (size_t)len * sizeof(float));
+    memcpy(buf.data(), "\x93NUMPY\x01\x00", 8);
+    buf[8] = (unsigned char)(hlen & 255);
+    buf[9] = (unsigned char)(hlen >> 8);
+    memcpy(buf.data() + 10, dict, (size_t)dn);
+    memset(buf.data() + 10 + dn, ' ', pad);
+    buf[10 + hlen - 1] = '\n';
+    memcpy(buf.data() + 10 + hlen, row, (size_t)len * sizeof(float));
+    const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0644);
+    if (fd < 0)
+        return FX_IO_EOPEN;
+    const unsigned char *p = buf.data();
+    size_t n = buf.size();
+    int st = FX_IO_OK;
+    while (n) {
+        const ssize_t w = write(fd, p, n);
+        if (w <= 0) {
+            st = FX_IO_EREAD;
+            break;
+        }
+        p += w;
+        n -= (size_t)w;
+    }
+    if (close(fd) != 0 && st == FX_IO_OK)
+        st = FX_IO_EREAD;
+    return st;
+}
+
+template <typename F>
+void parallel_for(int64_t n, int n_threads, F fn)
+{
+    n_threads = n_threads < 1 ? 1 : (n_threads > 64 ? 64 : n_threads);
+    if ((int64_t)n_threads > n)
+        n_threads = (int)(n > 0 ? n : 1);
+    std::atomic<int64_t> next(0);
+    auto body = [&]() {
+        for (;;) {
+            const int64_t i0 = next.fetch_add(16);
+            if (i0 >= n)
+                return;
+            const int64_t i1 = i0 + 16 < n ? i0 + 16 : n;
+            for (int64_t i = i0; i < i1; i++)
+                fn(i);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < n_threads; t++)
+        pool.emplace_back(body);
+    body();
+    for (auto &th : pool)
+        th.join();
+}
+
+}  // namespace
+
+extern "C" int fx_read_npy_points_f32(const char *const *paths, int64_t n, int64_t rows, float *out,
+                                      int32_t *status, int64_t *rows_found, int n_threads)
+{
+    if (n < 0 || rows < 0 || (n > 0 && (!paths || !out || !status || !rows_found))) {
+        fx_set_error("fx_read_npy_points_f32: bad arguments (n = %lld, rows = %lld)", (long long)n, (long long)rows);
+        return FX_EINVAL;
+    }
+    parallel_for(n, n_threads, [&](int64_t i) {
+        rows_found[i] = -1;
+        status[i] = read_one_points(paths[i], rows, out + i * rows * 3, &rows_found[i]);
+    });
+    return FX_OK;
+}
+
+extern "C" int fx_write_npy_rows_f32(const char *const *paths, int64_t n, const float *data, int64_t row_len,
+                                     int32_t *status, int n_threads)
+{
+    if (n < 0 || row_len < 0 || (n > 0 && (!paths || !data || !status))) {
+        fx_set_error("fx_write_npy_rows_f32: bad arguments (n = %lld, row_len = %lld)", (long long)n,
+                     (long long)row_len);
+        return FX_EINVAL;
+    }
+    parallel_for(n, n_threads, [&](int64_t i) { status[i] = write_one_row(paths[i], data + i * row_len, row_len); });
+    return FX_OK;
+}

@@ -176,46 +176,54 @@ def _log_error(reports_dir: Path, where, kind: str, msg) -> None:
         pass
 
 
-def process_samples(tasks: Iterable[Tuple[str, str, Dict[str, Any]]]) -> List[Dict[str, Any]]:
-    """Batched process_sample_worker: decodes every view of every sample on the
-    host, then per distinct (view size, settings) one silhouette call, one
-    moment launch and one group mean/std launch on the device; writes
-    <id>_hu.npy per sample and returns one {"success", "id", "vec", "note"}
-    dict per task in task order (reference :602-667).  Views that fail to load
-    are logged to <reports_dir>/read_errors.log and skipped; a sample without
-    usable views fails with note "failed: ..."."""
-    import torch
-    from . import engine
+def decode_samples(tasks: Iterable[Tuple[str, str, Dict[str, Any]]], workers: Optional[int] = None) -> Dict[str, Any]:
+    """Host half of process_samples: lists and decodes every view of every
+    task on a thread pool.  Views that fail to load are logged to
+    <reports_dir>/read_errors.log and skipped; a task whose directory cannot be
+    listed is marked failed."""
+    from . import ingest
 
     tasks = list(tasks)
+    workers = ingest.default_workers() if workers is None else int(workers)
     results: List[Dict[str, Any]] = []
-    views: List[np.ndarray] = []
-    owners: List[int] = []
-    keys: List[tuple] = []
+    jobs: List[Tuple[int, Path]] = []
     for k, (sample_id, dir_path_str, config) in enumerate(tasks):
         res = {"success": False, "id": sample_id, "vec": None, "note": ""}
         results.append(res)
         dir_path = Path(dir_path_str)
-        reports_dir = Path(config.get("reports_dir", "reports"))
         try:
             view_files = list_view_files(dir_path)
             if not view_files:
                 raise FileNotFoundError(f"No view images in {dir_path}")
             res["_n_files"] = len(view_files)
-            for vpath in view_files:
-                try:
-                    img = load_image(vpath)
-                    views.append(img)
-                    owners.append(k)
-                    keys.append((img.shape, int(config["resolution"]), float(config["crop_margin"]),
-                                 bool(config["preprocess_crop"]), bool(config["use_silhouette"]),
-                                 str(config["bg_color"])))
-                except Exception as e:
-                    _log_error(reports_dir, vpath, type(e).__name__, e)
+            jobs.extend((k, v) for v in view_files)
         except Exception as e:
-            _log_error(reports_dir, dir_path, type(e).__name__, e)
+            _log_error(Path(config.get("reports_dir", "reports")), dir_path, type(e).__name__, e)
             res["note"] = f"failed: {e}"
+    views: List[np.ndarray] = []
+    owners: List[int] = []
+    keys: List[tuple] = []
+    for (k, vpath), (ok, val) in zip(jobs, ingest.map_ordered(lambda j: load_image(j[1]), jobs, workers)):
+        config = tasks[k][2]
+        if not ok:
+            _log_error(Path(config.get("reports_dir", "reports")), vpath, type(val).__name__, val)
+            continue
+        views.append(val)
+        owners.append(k)
+        keys.append((val.shape, int(config["resolution"]), float(config["crop_margin"]),
+                     bool(config["preprocess_crop"]), bool(config["use_silhouette"]), str(config["bg_color"])))
+    return {"tasks": tasks, "results": results, "views": views, "owners": owners, "keys": keys, "workers": workers}
 
+
+def finish_samples(decoded: Dict[str, Any]) -> List[Dict[str, Any]]:
+    """Device half of process_samples: per distinct (view size, settings) one
+    silhouette call, one moment launch and one group mean/std launch; writes
+    <id>_hu.npy per sample."""
+    import torch
+    from . import engine, ingest
+
+    tasks, results = decoded["tasks"], decoded["results"]
+    views, owners, keys = decoded["views"], decoded["owners"], decoded["keys"]
     stats_by_task: Dict[int, np.ndarray] = {}
     # one pass per distinct (view size, settings): normally a single one
     for key in sorted(set(keys)):
@@ -224,7 +232,7 @@ def process_samples(tasks: Iterable[Tuple[str, str, Dict[str, Any]]]) -> List[Di
         uniq, counts = np.unique(np.asarray([owners[i] for i in idx], dtype=np.int64), return_counts=True)
         try:
             dev = _device()
-            raw = torch.from_numpy(np.stack([views[i] for i in idx])).to(dev)
+            raw = ingest.stack_to_device([views[i] for i in idx], dev, decoded["workers"])
             sil = engine.silhouette_batch(raw, resolution, crop_margin, preprocess_crop, info=not use_silhouette)
             if use_silhouette:
                 target = sil["mask"]
@@ -262,6 +270,17 @@ def process_samples(tasks: Iterable[Tuple[str, str, Dict[str, Any]]]) -> List[Di
     return results
 
 
+def process_samples(tasks: Iterable[Tuple[str, str, Dict[str, Any]]], workers: Optional[int] = None) -> List[Dict[str, Any]]:
+    """Batched process_sample_worker: decodes every view of every sample on a
+    host thread pool, then per distinct (view size, settings) one silhouette
+    call, one moment launch and one group mean/std launch on the device;
+    writes <id>_hu.npy per sample and returns one {"success", "id", "vec",
+    "note"} dict per task in task order (reference :602-667).  Views that fail
+    to load are logged to <reports_dir>/read_errors.log and skipped; a sample
+    without usable views fails with note "failed: ..."."""
+    return finish_samples(decode_samples(tasks, workers))
+
+
 def process_sample_worker(args_tuple: Tuple) -> Dict[str, Any]:
     """(sample_id, dir, config) -> {"success", "id", "vec", "note"} (reference :602-667)."""
     return process_samples([args_tuple])[0]
@@ -296,7 +315,8 @@ def parse_args(argv=None):
     p.add_argument("--crop_margin", type=float, default=0.05)
     p.add_argument("--bg_color", type=str, default="white", choices=["white", "black"])
     p.add_argument("--n_preview", type=int, default=0, help="accepted for compatibility; previews are not rendered")
-    p.add_argument("--workers", type=int, default=1, help="accepted for compatibility; the GPU batches instead")
+    p.add_argument("--workers", type=int, default=None,
+                   help="decode threads on the host (default: the cores, at most 16)")
     p.add_argument("--fast", action="store_true")
     p.add_argument("--max_samples", type=int, default=None)
     p.add_argument("--expected_views", type=int, default=12)
@@ -332,9 +352,14 @@ def main(argv=None) -> int:
               "overwrite": bool(args.overwrite), "reports_dir": str(reports_dir)}
     tasks = [(sid, str(d), config) for sid, d in ids]
     results: List[Dict[str, Any]] = []
+    if args.workers:
+        import os
+        os.environ["FX_DECODE_WORKERS"] = str(int(args.workers))
     step = max(1, int(args.batch_samples))
-    for i in range(0, len(tasks), step):
-        results.extend(process_samples(tasks[i:i + step]))
+    from . import ingest
+    # the next batch is decoded while the current one is on the device
+    for decoded in ingest.prefetch(decode_samples, (tasks[i:i + step] for i in range(0, len(tasks), step))):
+        results.extend(finish_samples(decoded))
     out_csv = out_dir / "hu_features_table.csv"
     append_to_csv(results_to_records(results), out_csv, overwrite=args.overwrite)
     try:
@@ -344,7 +369,7 @@ def main(argv=None) -> int:
     except Exception as e:
         logger.debug(f"Failed to write hu_feature_stats.csv: {e}")
     cfg = dict(config, timestamp=datetime.datetime.now().isoformat(sep=" ", timespec="seconds"),
-               views_dir=str(views_dir), workers=int(args.workers), seed=int(args.seed))
+               views_dir=str(views_dir), workers=args.workers, seed=int(args.seed))
     try:
         import yaml
         with open(out_dir / "extract_2d_hu_config.yaml", "w", encoding="utf-8") as fh:

@@ -75,11 +75,14 @@ def compute_pca_features_batch(point_sets: Sequence[np.ndarray], n_bins: int = 8
         return (empty, np.zeros((0, 6))) if return_eig else empty
     dims = 3 if sets[0].shape[1] >= 3 else 2
     sizes = np.array([p.shape[0] for p in sets], dtype=np.int64)
-    flat = np.concatenate([np.ascontiguousarray(p[:, :dims], dtype=np.float32) for p in sets], axis=0)
-    d_pts = torch.from_numpy(flat).to(dev)
     if np.all(sizes == sizes[0]):
-        res = engine.pca_batch(d_pts.view(len(sets), int(sizes[0]), dims), None, n_bins, normalize, eig=return_eig)
+        from . import ingest
+        d_pts = ingest.stack_to_device([np.ascontiguousarray(p[:, :dims], dtype=np.float32) for p in sets], dev,
+                                       ingest.default_workers())
+        res = engine.pca_batch(d_pts, None, n_bins, normalize, eig=return_eig)
     else:
+        flat = np.concatenate([np.ascontiguousarray(p[:, :dims], dtype=np.float32) for p in sets], axis=0)
+        d_pts = torch.from_numpy(flat).to(dev)
         off = np.zeros(len(sets) + 1, dtype=np.int64)
         np.cumsum(sizes, out=off[1:])
         res = engine.pca_batch(d_pts, torch.from_numpy(off).to(dev), n_bins, normalize, eig=return_eig)
@@ -140,49 +143,123 @@ def _fill_record(record: dict, n_pts: int, vec: np.ndarray, desc_path: Path) -> 
     record["descriptor_path"] = str(desc_path.resolve())
 
 
-def process_files(tasks: Iterable[tuple]) -> List[dict]:
-    """Batched process_file: loads every file on the host, runs one kernel
-    launch over all loadable sets, saves pca_<id>.npy per set and returns one
-    result dict per task, in task order, with the reference's layout
-    ({"success", "record", "error"}, :194-262)."""
+def load_files(tasks: Iterable[tuple], workers: Optional[int] = None) -> dict:
+    """Host half of process_files.  Files with the batch's common row count
+    (float32/float64, C order) are read by native threads straight into one
+    page-locked block; the others go through np.load one by one.  Files that
+    cannot be read or hold fewer than 3 points get their failed result here
+    (reference :194-230)."""
+    import os
+    from . import ingest
+
     tasks = list(tasks)
-    results: List[Optional[dict]] = [None] * len(tasks)
-    loaded = []
-    for k, t in enumerate(tasks):
-        (file_path_str, _sampled, out_dir_str, n_bins, normalize, _overwrite, manifest_map, reports_dir_str) = t
-        file_path = Path(file_path_str)
-        manifest_map = manifest_map if isinstance(manifest_map, dict) else {}
-        record = _blank_record(file_path, manifest_map)
+    workers = ingest.default_workers() if workers is None else int(workers)
+    n = len(tasks)
+    results: List[Optional[dict]] = [None] * n
+    records: List[dict] = []
+    for t in tasks:
+        stem = os.path.splitext(os.path.basename(t[0]))[0]
+        mm = t[6] if isinstance(t[6], dict) else {}
+        records.append({"id": stem, "raw_path": mm.get(stem, ""), "n_points": None,
+                        "lambda1": None, "lambda2": None, "lambda3": None, "r1": None, "r2": None, "r3": None,
+                        "ratio12": None, "ratio23": None, "trace": None, "proj_hist": None, "descriptor_path": ""})
+    rows = -1
+    for t in tasks[:8]:          # the common row count, from the first header that can be read
+        rows = ingest.npy_rows(t[0])
+        if rows >= 3:
+            break
+    block = owner = None
+    status = np.full(n, -1, dtype=np.int32)
+    if rows >= 3 and n:
+        block, owner = ingest.host_buffer((n, rows, 3), np.float32)
+        status, _found = ingest.read_points_batch([t[0] for t in tasks], rows, block, workers)
+    others = []                  # (k, float32 [N, 3]) of files the native reader left
+    for k in np.nonzero(status != 0)[0].tolist():
+        t = tasks[k]
         try:
-            pts = load_sample(file_path)
+            pts = ingest.read_npy_points(Path(t[0]))
             if int(pts.shape[0]) < 3:
                 raise ValueError("too few points (<3) after loading")
-            loaded.append((k, pts, record, Path(out_dir_str), int(n_bins), bool(normalize)))
+            others.append((k, pts))
         except Exception as e:
-            _log_error(Path(reports_dir_str), file_path, e)
-            results[k] = {"success": False, "record": record, "error": str(e)}
-    # one launch per (n_bins, normalize) combination present
+            _log_error(Path(t[7]), Path(t[0]), e)
+            results[k] = {"success": False, "record": records[k], "error": str(e)}
+    return {"tasks": tasks, "results": results, "records": records, "rows": rows, "block": block, "owner": owner,
+            "in_block": np.nonzero(status == 0)[0], "others": others, "workers": workers}
+
+
+def finish_files(batch: dict) -> List[dict]:
+    """Device half of process_files: one launch per (n_bins, normalize)
+    combination and storage form present, pca_<id>.npy per set written by
+    native threads, result dicts in task order."""
+    import os
+    import torch
+    from . import engine, ingest
+
+    tasks, results, records = batch["tasks"], batch["results"], batch["records"]
+    workers = batch["workers"]
+    done: List[tuple] = []       # (task indices, float32 [m, 9 + n_bins], point counts)
+
+    def fail(ks, e):
+        for k in ks:
+            _log_error(Path(tasks[k][7]), Path(tasks[k][0]), e)
+            results[k] = {"success": False, "record": records[k], "error": str(e)}
+
+    in_block = batch["in_block"]
+    if len(in_block):
+        settings = {(int(tasks[k][3]), bool(tasks[k][4])) for k in in_block.tolist()}
+        for (n_bins, normalize) in sorted(settings):
+            ks = np.asarray([k for k in in_block.tolist() if (int(tasks[k][3]), bool(tasks[k][4])) == (n_bins, normalize)],
+                            dtype=np.int64)
+            try:
+                host = batch["owner"]
+                if len(ks) != host.shape[0]:
+                    host = host[torch.from_numpy(ks)]
+                d_pts = host.to(_device(), non_blocking=True)
+                vecs = engine.pca_batch(d_pts, None, n_bins, normalize)["out"].cpu().numpy()
+                done.append((ks.tolist(), vecs, [batch["rows"]] * len(ks)))
+            except Exception as e:
+                fail(ks.tolist(), e)
     groups = {}
-    for item in loaded:
-        groups.setdefault((item[4], item[5]), []).append(item)
+    for k, pts in batch["others"]:
+        groups.setdefault((int(tasks[k][3]), bool(tasks[k][4])), []).append((k, pts))
     for (n_bins, normalize), items in groups.items():
         try:
-            vecs = compute_pca_features_batch([it[1] for it in items], n_bins=n_bins, normalize=normalize)
-            err = None
+            vecs = compute_pca_features_batch([p for _, p in items], n_bins=n_bins, normalize=normalize)
+            done.append(([k for k, _ in items], vecs, [int(p.shape[0]) for _, p in items]))
         except Exception as e:
-            vecs, err = None, e
-        for j, (k, pts, record, out_dir, _nb, _nz) in enumerate(items):
-            file_path = Path(tasks[k][0])
-            try:
-                if err is not None:
-                    raise err
-                desc_path = save_descriptor(file_path.stem, vecs[j], out_dir)
-                _fill_record(record, int(pts.shape[0]), vecs[j], desc_path)
-                results[k] = {"success": True, "record": record, "error": ""}
-            except Exception as e:
-                _log_error(Path(tasks[k][7]), file_path, e)
-                results[k] = {"success": False, "record": record, "error": str(e)}
+            fail([k for k, _ in items], e)
+
+    keys = ["lambda1", "lambda2", "lambda3", "r1", "r2", "r3", "ratio12", "ratio23", "trace"]
+    for ks, vecs, counts in done:
+        out_dirs = {tasks[k][2] for k in ks}
+        real = {}
+        for d in out_dirs:
+            os.makedirs(d, exist_ok=True)
+            real[d] = os.path.realpath(d)
+        paths = [os.path.join(real[tasks[k][2]], f"pca_{records[k]['id']}.npy") for k in ks]
+        status = ingest.write_rows_batch(paths, vecs, workers)
+        as_list = vecs.astype(np.float64).tolist()
+        for j, k in enumerate(ks):
+            if status[j] != 0:
+                fail([k], OSError(f"could not write {paths[j]} (status {int(status[j])})"))
+                continue
+            rec = records[k]
+            row = as_list[j]
+            rec.update(zip(keys, row[:9]))
+            rec["n_points"] = counts[j]
+            rec["proj_hist"] = row[9:]
+            rec["descriptor_path"] = paths[j]
+            results[k] = {"success": True, "record": rec, "error": ""}
     return results  # type: ignore[return-value]
+
+
+def process_files(tasks: Iterable[tuple], workers: Optional[int] = None) -> List[dict]:
+    """Batched process_file: reads every file on a host thread pool, runs one
+    kernel launch over all loadable sets, saves pca_<id>.npy per set and
+    returns one result dict per task, in task order, with the reference's
+    layout ({"success", "record", "error"}, :194-262)."""
+    return finish_files(load_files(tasks, workers))
 
 
 def process_file(args_tuple):
@@ -215,7 +292,8 @@ def parse_args(argv=None):
     p.add_argument("--max_samples", type=int, default=None)
     p.add_argument("--fast", action="store_true", help="process the first 20 files only")
     p.add_argument("--normalize", action="store_true")
-    p.add_argument("--workers", type=int, default=1, help="accepted for compatibility; the GPU batches instead")
+    p.add_argument("--workers", type=int, default=None, help="reader threads on the host (default: the cores, at most 16)")
+    p.add_argument("--batch_files", type=int, default=65536, help="files per device batch")
     p.add_argument("--overwrite", action="store_true")
     p.add_argument("--processed_manifest", type=str, default="")
     p.add_argument("--reports_dir", type=str, default="../../reports")
@@ -251,7 +329,15 @@ def main(argv=None) -> int:
         return 0
     tasks = [(str(p), str(sampled_dir), str(out_dir), int(args.n_bins), bool(args.normalize), bool(args.overwrite),
               manifest_map, str(reports_dir)) for p in files]
-    results = process_files(tasks)
+    from . import ingest
+    if args.workers:
+        import os
+        os.environ["FX_DECODE_WORKERS"] = str(int(args.workers))
+    step = max(1, int(args.batch_files))
+    results: List[dict] = []
+    # the next batch is read while the current one is on the device
+    for batch in ingest.prefetch(load_files, (tasks[i:i + step] for i in range(0, len(tasks), step))):
+        results.extend(finish_files(batch))
     records = [r["record"] for r in results if r.get("success")]
     if not records:
         logger.error("No descriptors produced (all files failed). Check reports/read_errors.log for details.")

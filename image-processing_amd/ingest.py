@@ -1,0 +1,184 @@
+"""File ingest for the extractors: threaded decode, pinned staging, overlapped
+host-to-device copies, one batch of lookahead.
+
+The reference reads one file per pool task (load_image, reference
+src/features/extract_2d_hu.py:84-98; load_sample,
+src/features/extract_3d_pca_features.py:48-56) and computes on the same core.
+Here the device finishes a batch in microseconds, so the host side is what
+sets files per second: decoding runs on a thread pool (PIL and NumPy release
+the GIL while they inflate / read), decoded arrays are packed into page-locked
+memory and copied on a side stream, and the next batch is decoded while the
+current one is on the device.
+"""
+from __future__ import annotations
+
+import os
+import threading
+from concurrent.futures import ThreadPoolExecutor
+from typing import Any, Callable, Iterable, Iterator, List, Sequence, Tuple
+
+import numpy as np
+
+
+def default_workers() -> int:
+    """Decode threads: the host cores, at most 16 (one GPU's share of a node)."""
+    env = os.environ.get("FX_DECODE_WORKERS")
+    if env:
+        return max(1, int(env))
+    return max(1, min(16, os.cpu_count() or 1))
+
+
+def map_ordered(fn: Callable[[Any], Any], items: Sequence[Any], workers: int) -> List[Tuple[bool, Any]]:
+    """fn over items on a thread pool; one (True, value) or (False, exception)
+    per item, in item order.  An exception in one item never hides another."""
+    def guarded(x):
+        try:
+            return True, fn(x)
+        except Exception as e:  # the caller logs it per file
+            return False, e
+
+    items = list(items)
+    if workers <= 1 or len(items) <= 1:
+        return [guarded(x) for x in items]
+    with ThreadPoolExecutor(max_workers=min(workers, len(items))) as pool:
+        return list(pool.map(guarded, items))
+
+
+def read_npy_points(path) -> np.ndarray:
+    """First three columns of an [N, >=3] .npy file as float32 [N, 3];
+    ValueError on any other shape.  float32 files are read without widening
+    (the reference widens to float64 and the descriptor is evaluated from the
+    float32 values either way)."""
+    arr = np.load(path, allow_pickle=False, mmap_mode=None)
+    if arr.ndim != 2 or arr.shape[1] < 3:
+        raise ValueError(f"invalid shape {arr.shape} (expected Nx3) for {path}")
+    return np.ascontiguousarray(arr[:, :3], dtype=np.float32)
+
+
+def _path_array(paths: Sequence[str]):
+    import ctypes
+    arr = (ctypes.c_char_p * len(paths))()
+    arr[:] = [os.fsencode(p) for p in paths]
+    return arr
+
+
+def host_buffer(shape, dtype=np.float32):
+    """A host array for staging: page-locked when a HIP device is present (so
+    that the later copy is asynchronous), ordinary memory otherwise.  Returns
+    (numpy view, owner to keep alive / to copy from)."""
+    import torch
+    tdtype = torch.from_numpy(np.empty(0, dtype=dtype)).dtype
+    t = torch.empty(tuple(shape), dtype=tdtype, pin_memory=torch.cuda.is_available())
+    return t.numpy(), t
+
+
+def read_points_batch(paths: Sequence[str], rows: int, out: np.ndarray, workers: int):
+    """Native batch read of [rows, >=3] float32/float64 .npy files into
+    out[i] (float32 [n, rows, 3]).  Returns (status int32 [n], rows_found int64
+    [n]); status 0 = read, anything else = left to the caller."""
+    from . import _lib
+    n = len(paths)
+    status = np.zeros(n, dtype=np.int32)
+    found = np.zeros(n, dtype=np.int64)
+    if n == 0:
+        return status, found
+    assert out.dtype == np.float32 and out.flags.c_contiguous and out.shape == (n, rows, 3)
+    _lib.call("fx_read_npy_points_f32", _path_array(paths), n, int(rows), out.ctypes.data, status.ctypes.data,
+              found.ctypes.data, int(workers))
+    return status, found
+
+
+def write_rows_batch(paths: Sequence[str], data: np.ndarray, workers: int) -> np.ndarray:
+    """Native batch np.save of the float32 rows of `data` to `paths`; returns
+    the per-file status (0 = written)."""
+    from . import _lib
+    n = len(paths)
+    status = np.zeros(n, dtype=np.int32)
+    if n == 0:
+        return status
+    data = np.ascontiguousarray(data, dtype=np.float32)
+    assert data.ndim == 2 and data.shape[0] == n
+    _lib.call("fx_write_npy_rows_f32", _path_array(paths), n, data.ctypes.data, int(data.shape[1]),
+              status.ctypes.data, int(workers))
+    return status
+
+
+def npy_rows(path) -> int:
+    """Row count from the header of a 2-D .npy file (no data read); -1 if it cannot be told."""
+    try:
+        arr = np.load(path, allow_pickle=False, mmap_mode="r")
+        return int(arr.shape[0]) if arr.ndim == 2 else -1
+    except Exception:
+        return -1
+
+
+def stack_to_device(arrays: Sequence[np.ndarray], device, workers: int = 1):
+    """Equally shaped arrays -> one device tensor [n, ...] through page-locked
+    memory and an asynchronous copy on a side stream; the current stream is
+    made to wait for the copy, the host is not."""
+    import torch
+
+    first = np.asarray(arrays[0])
+    staging = torch.empty((len(arrays),) + first.shape, dtype=torch.from_numpy(np.empty(0, dtype=first.dtype)).dtype,
+                          pin_memory=True)
+    view = staging.numpy()
+
+    def put(i):
+        view[i] = arrays[i]
+
+    if workers > 1 and len(arrays) * first.nbytes > (8 << 20):
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            list(pool.map(put, range(len(arrays))))
+    else:
+        for i in range(len(arrays)):
+            put(i)
+    side = _copy_stream(device)
+    side.wait_stream(torch.cuda.current_stream(device))
+    with torch.cuda.stream(side):
+        out = staging.to(device, non_blocking=True)
+    torch.cuda.current_stream(device).wait_stream(side)
+    # both buffers must outlive the copy: tie them to the consuming stream
+    out.record_stream(torch.cuda.current_stream(device))
+    _keep_alive(staging, side)
+    return out
+
+
+_streams = {}
+_pending: List[Tuple[Any, Any]] = []
+_lock = threading.Lock()
+
+
+def _copy_stream(device):
+    import torch
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    with _lock:
+        if key not in _streams:
+            _streams[key] = torch.cuda.Stream(device=device)
+        return _streams[key]
+
+
+def _keep_alive(staging, stream) -> None:
+    """Holds the pinned buffer until the copy that reads it has finished."""
+    import torch
+    ev = torch.cuda.Event()
+    ev.record(stream)
+    with _lock:
+        _pending.append((ev, staging))
+        _pending[:] = [(e, s) for e, s in _pending if not e.query()]
+
+
+def prefetch(produce: Callable[[Any], Any], batches: Iterable[Any]) -> Iterator[Any]:
+    """Yields produce(batch) for every batch in order while produce() of the
+    next batch already runs on a background thread (one batch of lookahead).
+    An exception raised by produce() is re-raised at the position of its batch."""
+    it = iter(batches)
+    with ThreadPoolExecutor(max_workers=1) as pool:
+        try:
+            fut = pool.submit(produce, next(it))
+        except StopIteration:
+            return
+        for nxt in it:
+            nfut = pool.submit(produce, nxt)
+            yield fut.result()
+            fut = nfut
+        yield fut.result()

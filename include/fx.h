@@ -167,6 +167,38 @@ int fx_gray_fit_batch_u8(const uint8_t *d_img, int64_t B, int H, int W,
                          int resolution, int bg_value, uint8_t *d_out, void *stream);
 
 /*
+ * Host file I/O on native threads (no device work).  Per-file status codes:
+ */
+#define FX_IO_OK 0
+#define FX_IO_EOPEN 1    /* cannot open / create */
+#define FX_IO_EREAD 2    /* short read or write */
+#define FX_IO_EFORMAT 3  /* not an .npy file, or a header this reader does not parse */
+#define FX_IO_EDTYPE 4   /* not little-endian float32/float64 in C order */
+#define FX_IO_ESHAPE 5   /* not 2-D with at least 3 columns */
+#define FX_IO_EROWS 6    /* 2-D float array with a row count other than `rows` (rows_found tells it) */
+
+/*
+ * Batch form of load_sample, src/features/extract_3d_pca_features.py:48-56
+ * (np.load + [:, :3]): reads n .npy files that each hold a [rows, >=3]
+ * float32/float64 array and writes the first three columns as float32 into
+ * out[i] (n x rows x 3, host memory, e.g. page-locked).  A file that does not
+ * fit gets a status and is left for the caller (np.load handles every other
+ * dtype and raises the reference's errors); status[i] / rows_found[i] per file.
+ */
+int fx_read_npy_points_f32(const char *const *paths, int64_t n, int64_t rows,
+                           float *out, int32_t *status, int64_t *rows_found,
+                           int n_threads);
+
+/*
+ * Batch form of save_descriptor, src/features/extract_3d_pca_features.py:148-158
+ * (np.save of a 1-D float32 vector, allow_pickle=False): writes row i of
+ * data (n x row_len float32, host memory) to paths[i], byte-identical to
+ * np.save.
+ */
+int fx_write_npy_rows_f32(const char *const *paths, int64_t n, const float *data,
+                          int64_t row_len, int32_t *status, int n_threads);
+
+/*
  * Synthetic inputs for benchmarks and parity tests (no reference counterpart:
  * the reference reads rendered PNG views and sampled .npy clouds from disk).
  * Image `first_index + b` / set `first_index + b` depends only on (seed, that

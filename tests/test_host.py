@@ -193,3 +193,101 @@ def test_shape_generator_is_pinned():
 
 
 SHAPES_DIGEST = "001432d52080e1ef253a3ca2f8498fb0a57fd8c926fbe152156c9839746d3aae"
+
+
+# ------------------------------------------------------------ ingest helpers
+def test_map_ordered_keeps_order_and_isolates_errors():
+    ing = pkg("ingest")
+
+    def f(x):
+        if x % 5 == 3:
+            raise ValueError(f"bad {x}")
+        return x * x
+
+    for workers in (1, 4):
+        out = ing.map_ordered(f, range(23), workers)
+        assert len(out) == 23
+        for x, (ok, val) in enumerate(out):
+            if x % 5 == 3:
+                assert not ok and isinstance(val, ValueError) and str(val) == f"bad {x}"
+            else:
+                assert ok and val == x * x
+    assert ing.map_ordered(f, [], 4) == []
+
+
+def test_prefetch_order_lookahead_and_errors():
+    import threading
+    ing = pkg("ingest")
+    seen = []
+    lock = threading.Lock()
+
+    def produce(b):
+        with lock:
+            seen.append(b)
+        if b == 3:
+            raise RuntimeError("batch 3")
+        return b * 10
+
+    got = []
+    with pytest.raises(RuntimeError, match="batch 3"):
+        for v in ing.prefetch(produce, range(6)):
+            got.append(v)
+            if v == 0:
+                assert 1 in seen or True   # the next batch may already be running
+    assert got == [0, 10, 20]
+    assert list(ing.prefetch(produce, [])) == []
+    assert list(ing.prefetch(lambda b: b + 1, [7])) == [8]
+
+
+def test_read_npy_points(tmp_path):
+    ing = pkg("ingest")
+    a = np.random.default_rng(0).normal(size=(50, 6))
+    np.save(tmp_path / "a.npy", a)
+    got = ing.read_npy_points(tmp_path / "a.npy")
+    assert got.dtype == np.float32 and got.shape == (50, 3) and got.flags.c_contiguous
+    np.testing.assert_array_equal(got, a[:, :3].astype(np.float32))
+    np.save(tmp_path / "b.npy", np.zeros((4, 2)))
+    with pytest.raises(ValueError, match="invalid shape"):
+        ing.read_npy_points(tmp_path / "b.npy")
+
+
+def test_native_npy_batch_io(tmp_path):
+    """fx_read_npy_points_f32 / fx_write_npy_rows_f32 (host threads, no device work)."""
+    ing, lib = pkg("ingest"), pkg("_lib")
+    rng = np.random.default_rng(1)
+    pts = rng.normal(size=(40, 64, 3)).astype(np.float32)
+    paths = []
+    for i in range(40):
+        p = tmp_path / f"c{i:02d}.npy"
+        np.save(p, pts[i])
+        paths.append(str(p))
+    np.save(paths[3], pts[3].astype(np.float64))                       # widened file: rounded back
+    np.save(paths[4], np.concatenate([pts[4], pts[4][:, :2]], axis=1))  # five columns: first three
+    np.save(paths[5], pts[5][:10])                                      # other row count
+    np.save(paths[6], np.asfortranarray(pts[6]))                        # Fortran order
+    np.save(paths[7], pts[7].astype(np.float16))                        # unsupported dtype
+    np.save(paths[8], pts[8][:, :2])                                    # two columns
+    Path(paths[9]).write_bytes(b"\x93NUMPY junk")
+    paths[10] = str(tmp_path / "missing.npy")
+    out = np.full((40, 64, 3), np.nan, dtype=np.float32)
+    status, found = ing.read_points_batch(paths, 64, out, 4)
+    expect = {5: lib.load() and 6, 6: 4, 7: 4, 8: 5, 9: 3, 10: 1}
+    for i in range(40):
+        if i in expect:
+            assert status[i] == expect[i], (i, status[i])
+        else:
+            assert status[i] == 0
+            np.testing.assert_array_equal(out[i], pts[i])
+    assert found[5] == 10 and found[0] == 64
+    assert ing.npy_rows(paths[0]) == 64 and ing.npy_rows(paths[9]) == -1
+
+    vec = rng.normal(size=(40, 17)).astype(np.float32)
+    outs = [str(tmp_path / f"pca_{i}.npy") for i in range(40)]
+    outs[2] = str(tmp_path / "no_such_dir" / "x.npy")
+    st = ing.write_rows_batch(outs, vec, 4)
+    assert st[2] == 1 and (np.delete(st, 2) == 0).all()
+    for i in (0, 1, 39):
+        np.save(tmp_path / "ref.npy", vec[i])
+        assert Path(outs[i]).read_bytes() == (tmp_path / "ref.npy").read_bytes()
+        np.testing.assert_array_equal(np.load(outs[i], allow_pickle=False), vec[i])
+    assert len(ing.write_rows_batch([], np.zeros((0, 17), np.float32), 4)) == 0

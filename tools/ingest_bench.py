@@ -1,0 +1,106 @@
+"""End-to-end files per second of the two extractors, from files on disk to the
+feature tables: writes a synthetic data set (S samples x V PNG views, C point
+clouds as .npy) into a scratch directory, then runs the package's main()
+functions on it and prints one JSON line.
+
+    python tools/ingest_bench.py [--samples 400] [--views 12] [--clouds 20000] [--workers 16]
+
+The decode rate of the host (PIL PNG inflate, np.load) bounds this number; the
+device work is a few milliseconds for the whole set.
+"""
+import argparse
+import importlib
+import json
+import shutil
+import sys
+import tempfile
+import time
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+
+import numpy as np
+import torch
+from PIL import Image
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--samples", type=int, default=400)
+    ap.add_argument("--views", type=int, default=12)
+    ap.add_argument("--clouds", type=int, default=20000)
+    ap.add_argument("--workers", type=int, default=16)
+    ap.add_argument("--dir", default=None)
+    a = ap.parse_args()
+
+    eng = importlib.import_module("image-processing_amd.engine")
+    hu = importlib.import_module("image-processing_amd.extract_2d_hu")
+    pca = importlib.import_module("image-processing_amd.extract_3d_pca_features")
+    dev = torch.device("cuda", 0)
+    root = Path(tempfile.mkdtemp(prefix="fx_ingest_", dir=a.dir))
+    try:
+        # ---- data set
+        n_img = a.samples * a.views
+        shapes = eng.synth_shapes(n_img, 224, 224, seed=7, device=dev).to(torch.float32)
+        g = torch.Generator(device=dev)
+        g.manual_seed(7)
+        gray = (235.0 - shapes * (195.0 / 255.0) + torch.randn(shapes.shape, generator=g, device=dev) * 8.0)
+        gray = gray.clamp_(0, 255).round_().to(torch.uint8).cpu().numpy()
+        views = root / "views"
+        for s in range(a.samples):
+            (views / f"tree_{s:05d}").mkdir(parents=True)
+
+        def save_png(i):
+            s, v = divmod(i, a.views)
+            Image.fromarray(gray[i]).save(views / f"tree_{s:05d}" / f"view_{v + 1:02d}.png")
+
+        with ThreadPoolExecutor(a.workers) as pool:
+            list(pool.map(save_png, range(n_img)))
+        pts = eng.synth_points(a.clouds, 1024, seed=7, device=dev).cpu().numpy()
+        sampled = root / "sampled"
+        sampled.mkdir()
+
+        def save_npy(i):
+            np.save(sampled / f"tree_{i:06d}.npy", pts[i])
+
+        with ThreadPoolExecutor(a.workers) as pool:
+            list(pool.map(save_npy, range(a.clouds)))
+        png_bytes = sum(p.stat().st_size for p in views.rglob("*.png"))
+
+        # ---- warm the library outside the timed runs
+        eng.silhouette_batch(torch.zeros((2, 224, 224), dtype=torch.uint8, device=dev), 224)
+        eng.pca_batch(torch.zeros((2, 1024, 3), device=dev))
+        torch.cuda.synchronize()
+
+        out = {"views": n_img, "clouds": a.clouds, "workers": a.workers, "png_bytes": png_bytes}
+        t0 = time.perf_counter()
+        rc = hu.main(["--views_dir", str(views), "--out_dir", str(root / "hu"), "--reports_dir", str(root / "rep"),
+                      "--use_silhouette", "--preprocess_crop", "--overwrite", "--workers", str(a.workers),
+                      "--batch_samples", "256"])
+        t_hu = time.perf_counter() - t0
+        assert rc == 0
+        out["hu_seconds"] = t_hu
+        out["views_per_s"] = n_img / t_hu
+
+        # decode alone, to show what bounds the figure above
+        t0 = time.perf_counter()
+        ing = importlib.import_module("image-processing_amd.ingest")
+        files = sorted(views.rglob("*.png"))
+        ing.map_ordered(hu.load_image, files, a.workers)
+        out["decode_only_views_per_s"] = n_img / (time.perf_counter() - t0)
+
+        t0 = time.perf_counter()
+        rc = pca.main(["--sampled_dir", str(sampled), "--out_dir", str(root / "desc"), "--reports_dir",
+                       str(root / "rep"), "--overwrite", "--workers", str(a.workers)])
+        t_pca = time.perf_counter() - t0
+        assert rc == 0
+        out["pca_seconds"] = t_pca
+        out["clouds_per_s"] = a.clouds / t_pca
+        print(json.dumps(out), flush=True)
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()
