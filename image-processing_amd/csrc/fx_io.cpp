@@ -19,6 +19,7 @@
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <zlib.h>
 
 #include "../../include/fx.h"
 
@@ -200,6 +201,144 @@ int write_one_row(const char *path, const float *row, int64_t len)
     return st;
 }
 
+// ------------------------------------------------------------------ PNG
+// Decoder for the PNG files a renderer writes: 8 bits per sample, colour type
+// gray, gray + alpha, RGB or RGBA, not interlaced, no tRNS chunk.  Everything
+// else (palette, 16 bit, interlace, transparency key, a damaged file) is
+// reported and left to PIL, so that what PIL accepts, rejects or converts
+// differently never depends on this code.  Gray conversion as PIL's
+// convert("L"): (R * 19595 + G * 38470 + B * 7471 + 0x8000) >> 16, alpha ignored.
+inline uint32_t be32(const unsigned char *p)
+{
+    return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3];
+}
+
+inline int paeth(int a, int b, int c)
+{
+    const int p = a + b - c;
+    const int pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+    return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+
+int decode_one_png(const char *path, int want_h, int want_w, uint8_t *out, int32_t *found_hw)
+{
+    const int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0)
+        return FX_IO_EOPEN;
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || sb.st_size < 8 + 25 + 12 || sb.st_size > (off_t)(1u << 30)) {
+        close(fd);
+        return FX_IO_EFORMAT;
+    }
+    std::vector<unsigned char> file((size_t)sb.st_size);
+    const bool ok = read_fully(fd, file.data(), file.size(), 0);
+    close(fd);
+    if (!ok)
+        return FX_IO_EREAD;
+    static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    if (memcmp(file.data(), sig, 8) != 0)
+        return FX_IO_EFORMAT;
+    size_t pos = 8;
+    int width = 0, height = 0, channels = 0;
+    bool have_ihdr = false, have_iend = false;
+    std::vector<unsigned char> idat;
+    while (pos + 12 <= file.size()) {
+        const uint32_t len = be32(&file[pos]);
+        const unsigned char *type = &file[pos + 4];
+        if ((size_t)len > file.size() - pos - 12)
+            return FX_IO_EFORMAT;
+        const unsigned char *data = &file[pos + 8];
+        if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), type, (uInt)(len + 4)) != be32(data + len))
+            return FX_IO_EFORMAT;
+        if (memcmp(type, "IHDR", 4) == 0) {
+            if (len != 13 || have_ihdr)
+                return FX_IO_EFORMAT;
+            have_ihdr = true;
+            width = (int)be32(data);
+            height = (int)be32(data + 4);
+            const int depth = data[8], ctype = data[9], interlace = data[12];
+            if (depth != 8 || interlace != 0 || data[10] != 0 || data[11] != 0)
+                return FX_IO_EDTYPE;
+            channels = ctype == 0 ? 1 : ctype == 4 ? 2 : ctype == 2 ? 3 : ctype == 6 ? 4 : 0;
+            if (!channels)
+                return FX_IO_EDTYPE;
+            if (width <= 0 || height <= 0)
+                return FX_IO_EFORMAT;
+            found_hw[0] = height;
+            found_hw[1] = width;
+            if (width != want_w || height != want_h)
+                return FX_IO_EROWS;
+        } else if (!have_ihdr) {
+            return FX_IO_EFORMAT;
+        } else if (memcmp(type, "IDAT", 4) == 0) {
+            idat.insert(idat.end(), data, data + len);
+        } else if (memcmp(type, "tRNS", 4) == 0 || memcmp(type, "PLTE", 4) == 0) {
+            return FX_IO_EDTYPE;
+        } else if (memcmp(type, "IEND", 4) == 0) {
+            have_iend = true;
+            break;
+        }
+        pos += 12 + (size_t)len;
+    }
+    if (!have_ihdr || !have_iend || idat.empty())
+        return FX_IO_EFORMAT;
+    const size_t stride = (size_t)width * channels;
+    std::vector<unsigned char> raw((size_t)height * (stride + 1));
+    uLongf raw_len = (uLongf)raw.size();
+    if (uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size()) != Z_OK || raw_len != raw.size())
+        return FX_IO_EFORMAT;
+    // undo the per-row filters in place
+    const int bpp = channels;
+    for (int y = 0; y < height; y++) {
+        unsigned char *row = raw.data() + (size_t)y * (stride + 1);
+        const int ft = row[0];
+        unsigned char *cur = row + 1;
+        const unsigned char *up = y ? cur - (stride + 1) : nullptr;
+        switch (ft) {
+        case 0:
+            break;
+        case 1:
+            for (size_t i = bpp; i < stride; i++)
+                cur[i] = (unsigned char)(cur[i] + cur[i - bpp]);
+            break;
+        case 2:
+            if (up)
+                for (size_t i = 0; i < stride; i++)
+                    cur[i] = (unsigned char)(cur[i] + up[i]);
+            break;
+        case 3:
+            for (size_t i = 0; i < stride; i++) {
+                const int a = i >= (size_t)bpp ? cur[i - bpp] : 0, b = up ? up[i] : 0;
+                cur[i] = (unsigned char)(cur[i] + ((a + b) >> 1));
+            }
+            break;
+        case 4:
+            for (size_t i = 0; i < stride; i++) {
+                const int a = i >= (size_t)bpp ? cur[i - bpp] : 0, b = up ? up[i] : 0;
+                const int c = (up && i >= (size_t)bpp) ? up[i - bpp] : 0;
+                cur[i] = (unsigned char)(cur[i] + paeth(a, b, c));
+            }
+            break;
+        default:
+            return FX_IO_EFORMAT;
+        }
+    }
+    for (int y = 0; y < height; y++) {
+        const unsigned char *cur = raw.data() + (size_t)y * (stride + 1) + 1;
+        uint8_t *o = out + (size_t)y * width;
+        if (channels <= 2) {
+            for (int x = 0; x < width; x++)
+                o[x] = cur[(size_t)x * channels];
+        } else {
+            for (int x = 0; x < width; x++) {
+                const unsigned char *p = cur + (size_t)x * channels;
+                o[x] = (uint8_t)((p[0] * 19595u + p[1] * 38470u + p[2] * 7471u + 0x8000u) >> 16);
+            }
+        }
+    }
+    return FX_IO_OK;
+}
+
 template <typename F>
 void parallel_for(int64_t n, int n_threads, F fn)
 {
@@ -250,5 +389,19 @@ extern "C" int fx_write_npy_rows_f32(const char *const *paths, int64_t n, const 
         return FX_EINVAL;
     }
     parallel_for(n, n_threads, [&](int64_t i) { status[i] = write_one_row(paths[i], data + i * row_len, row_len); });
+    return FX_OK;
+}
+
+extern "C" int fx_decode_png_gray_u8(const char *const *paths, int64_t n, int H, int W, uint8_t *out, int32_t *status,
+                                     int32_t *found_hw, int n_threads)
+{
+    if (n < 0 || H < 1 || W < 1 || (n > 0 && (!paths || !out || !status || !found_hw))) {
+        fx_set_error("fx_decode_png_gray_u8: bad arguments (n = %lld, %dx%d)", (long long)n, H, W);
+        return FX_EINVAL;
+    }
+    parallel_for(n, n_threads, [&](int64_t i) {
+        found_hw[2 * i] = found_hw[2 * i + 1] = -1;
+        status[i] = decode_one_png(paths[i], H, W, out + (size_t)i * H * W, found_hw + 2 * i);
+    });
     return FX_OK;
 }

@@ -177,8 +177,11 @@ def _log_error(reports_dir: Path, where, kind: str, msg) -> None:
 
 
 def decode_samples(tasks: Iterable[Tuple[str, str, Dict[str, Any]]], workers: Optional[int] = None) -> Dict[str, Any]:
-    """Host half of process_samples: lists and decodes every view of every
-    task on a thread pool.  Views that fail to load are logged to
+    """Host half of process_samples: lists every task's views and decodes
+    them.  PNG files of the batch's common size go through the native batch
+    decoder straight into one page-locked block; every other file (another
+    size or format, anything the native decoder does not take) is opened with
+    PIL on a thread pool.  Views that fail to load are logged to
     <reports_dir>/read_errors.log and skipped; a task whose directory cannot be
     listed is marked failed."""
     from . import ingest
@@ -200,55 +203,111 @@ def decode_samples(tasks: Iterable[Tuple[str, str, Dict[str, Any]]], workers: Op
         except Exception as e:
             _log_error(Path(config.get("reports_dir", "reports")), dir_path, type(e).__name__, e)
             res["note"] = f"failed: {e}"
+
+    def key_of(k: int, shape) -> tuple:
+        config = tasks[k][2]
+        return (tuple(shape), int(config["resolution"]), float(config["crop_margin"]),
+                bool(config["preprocess_crop"]), bool(config["use_silhouette"]), str(config["bg_color"]))
+
+    # native batch decode of the PNG files that share the first PNG's size
+    png = [j for j, (_, v) in enumerate(jobs) if v.suffix.lower() == ".png"]
+    size = None
+    for j in png[:8]:
+        size = ingest.image_size(jobs[j][1])
+        if size:
+            break
+    block = owner = None
+    native_ok = np.zeros(len(jobs), dtype=bool)
+    row_of = {}
+    if size and png:
+        block, owner = ingest.host_buffer((len(png), size[0], size[1]), np.uint8)
+        status, _found = ingest.decode_png_batch([str(jobs[j][1]) for j in png], size[0], size[1], block, workers)
+        for r, j in enumerate(png):
+            if status[r] == 0:
+                native_ok[j] = True
+                row_of[j] = r
+    rest = [j for j in range(len(jobs)) if not native_ok[j]]
     views: List[np.ndarray] = []
     owners: List[int] = []
     keys: List[tuple] = []
-    for (k, vpath), (ok, val) in zip(jobs, ingest.map_ordered(lambda j: load_image(j[1]), jobs, workers)):
-        config = tasks[k][2]
+    seq: List[int] = []          # position in the task-by-task, view-by-view order
+    for j, (ok, val) in zip(rest, ingest.map_ordered(lambda j: load_image(jobs[j][1]), rest, workers)):
+        k, vpath = jobs[j]
         if not ok:
-            _log_error(Path(config.get("reports_dir", "reports")), vpath, type(val).__name__, val)
+            _log_error(Path(tasks[k][2].get("reports_dir", "reports")), vpath, type(val).__name__, val)
             continue
         views.append(val)
         owners.append(k)
-        keys.append((val.shape, int(config["resolution"]), float(config["crop_margin"]),
-                     bool(config["preprocess_crop"]), bool(config["use_silhouette"]), str(config["bg_color"])))
-    return {"tasks": tasks, "results": results, "views": views, "owners": owners, "keys": keys, "workers": workers}
+        keys.append(key_of(k, val.shape))
+        seq.append(j)
+    in_block = [j for j in range(len(jobs)) if native_ok[j]]
+    block_owners = [jobs[j][0] for j in in_block]
+    return {"tasks": tasks, "results": results, "views": views, "owners": owners, "keys": keys, "seq": seq,
+            "workers": workers, "block": block, "block_owner_tensor": owner,
+            "block_rows": [row_of[j] for j in in_block], "block_owners": block_owners,
+            "block_keys": [key_of(k, size) for k in block_owners], "block_seq": in_block}
 
 
 def finish_samples(decoded: Dict[str, Any]) -> List[Dict[str, Any]]:
     """Device half of process_samples: per distinct (view size, settings) one
-    silhouette call, one moment launch and one group mean/std launch; writes
-    <id>_hu.npy per sample."""
+    silhouette call and one moment launch, then one group mean/std launch over
+    all samples (each sample's rows in file-name order, whatever the sizes of
+    its views); writes <id>_hu.npy per sample."""
     import torch
     from . import engine, ingest
 
     tasks, results = decoded["tasks"], decoded["results"]
     views, owners, keys = decoded["views"], decoded["owners"], decoded["keys"]
+    b_rows, b_owners, b_keys = decoded["block_rows"], decoded["block_owners"], decoded["block_keys"]
+    all_seq = np.asarray(list(decoded["block_seq"]) + list(decoded["seq"]), dtype=np.int64)
+    all_own = np.asarray(list(b_owners) + list(owners), dtype=np.int64)
     stats_by_task: Dict[int, np.ndarray] = {}
-    # one pass per distinct (view size, settings): normally a single one
-    for key in sorted(set(keys)):
-        idx = [i for i, kk in enumerate(keys) if kk == key]      # task order, so owners ascend
-        _, resolution, crop_margin, preprocess_crop, use_silhouette, bg_color = key
-        uniq, counts = np.unique(np.asarray([owners[i] for i in idx], dtype=np.int64), return_counts=True)
+    if len(all_seq):
         try:
             dev = _device()
-            raw = ingest.stack_to_device([views[i] for i in idx], dev, decoded["workers"])
-            sil = engine.silhouette_batch(raw, resolution, crop_margin, preprocess_crop, info=not use_silhouette)
-            if use_silhouette:
-                target = sil["mask"]
-            else:
-                target = engine.gray_fit_batch(raw, sil["info"], resolution, 255 if bg_color == "white" else 0)
+            order = np.argsort(all_seq, kind="stable")       # task by task, each sample's views in file-name order
+            rank = np.empty(len(order), dtype=np.int64)
+            rank[order] = np.arange(len(order))
+            rows_all = torch.zeros((len(order), 7), dtype=torch.float32, device=dev)
+            d_block = None
+            nb = len(b_rows)
+            # one pass per distinct (view size, settings): normally a single one
+            for key in sorted(set(keys) | set(b_keys)):
+                idx = [i for i, kk in enumerate(keys) if kk == key]
+                bidx = [i for i, kk in enumerate(b_keys) if kk == key]
+                _, resolution, crop_margin, preprocess_crop, use_silhouette, bg_color = key
+                try:
+                    parts = []
+                    if bidx:
+                        if d_block is None:
+                            d_block = decoded["block_owner_tensor"].to(dev, non_blocking=True)
+                        rows = [b_rows[i] for i in bidx]
+                        parts.append(d_block if rows == list(range(d_block.shape[0]))
+                                     else d_block[torch.as_tensor(rows, dtype=torch.int64, device=dev)])
+                    if idx:
+                        parts.append(ingest.stack_to_device([views[i] for i in idx], dev, decoded["workers"]))
+                    raw = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
+                    sil = engine.silhouette_batch(raw, resolution, crop_margin, preprocess_crop,
+                                                  info=not use_silhouette)
+                    if use_silhouette:
+                        target = sil["mask"]
+                    else:
+                        target = engine.gray_fit_batch(raw, sil["info"], resolution, 255 if bg_color == "white" else 0)
+                    where = rank[np.asarray(bidx + [nb + i for i in idx], dtype=np.int64)]
+                    rows_all[torch.from_numpy(where).to(dev)] = engine.hu_batch(target)["hulog7"]
+                except Exception as e:
+                    for k in {b_owners[i] for i in bidx} | {owners[i] for i in idx}:
+                        results[k]["note"] = f"failed: {e}"
+            uniq, counts = np.unique(all_own[order], return_counts=True)   # owners ascend along the order
             off = np.zeros(len(counts) + 1, dtype=np.int64)
             np.cumsum(counts, out=off[1:])
-            rows = engine.hu_batch(target)["hulog7"]
-            stats = engine.hu_groupstat(rows, torch.from_numpy(off).to(dev)).cpu().numpy()
+            stats = engine.hu_groupstat(rows_all, torch.from_numpy(off).to(dev)).cpu().numpy()
             for g, k in enumerate(uniq.tolist()):
-                if k in stats_by_task:      # views of one sample in two sizes: not a valid sample
-                    results[k]["note"] = "failed: views of different sizes"
                 stats_by_task[k] = stats[g]
         except Exception as e:
-            for k in uniq.tolist():
-                results[k]["note"] = f"failed: {e}"
+            for k in set(all_own.tolist()):
+                if not results[k]["note"].startswith("failed"):
+                    results[k]["note"] = f"failed: {e}"
 
     for k, (sample_id, dir_path_str, config) in enumerate(tasks):
         res = results[k]

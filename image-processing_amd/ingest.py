@@ -103,6 +103,33 @@ def write_rows_batch(paths: Sequence[str], data: np.ndarray, workers: int) -> np
     return status
 
 
+def decode_png_batch(paths: Sequence[str], H: int, W: int, out: np.ndarray, workers: int):
+    """Native batch decode of H x W PNG files to gray into out[i] (uint8
+    [n, H, W]).  Returns (status int32 [n], found int32 [n, 2] = height, width
+    as far as the header could be read); status 0 = decoded, anything else =
+    left to PIL."""
+    from . import _lib
+    n = len(paths)
+    status = np.zeros(n, dtype=np.int32)
+    found = np.full((n, 2), -1, dtype=np.int32)
+    if n == 0:
+        return status, found
+    assert out.dtype == np.uint8 and out.flags.c_contiguous and out.shape == (n, H, W)
+    _lib.call("fx_decode_png_gray_u8", _path_array(paths), n, int(H), int(W), out.ctypes.data, status.ctypes.data,
+              found.ctypes.data, int(workers))
+    return status, found
+
+
+def image_size(path):
+    """(height, width) from the file header, or None."""
+    try:
+        from PIL import Image
+        with Image.open(str(path)) as im:
+            return int(im.height), int(im.width)
+    except Exception:
+        return None
+
+
 def npy_rows(path) -> int:
     """Row count from the header of a 2-D .npy file (no data read); -1 if it cannot be told."""
     try:

@@ -173,9 +173,9 @@ int fx_gray_fit_batch_u8(const uint8_t *d_img, int64_t B, int H, int W,
 #define FX_IO_EOPEN 1    /* cannot open / create */
 #define FX_IO_EREAD 2    /* short read or write */
 #define FX_IO_EFORMAT 3  /* not an .npy file, or a header this reader does not parse */
-#define FX_IO_EDTYPE 4   /* not little-endian float32/float64 in C order */
+#define FX_IO_EDTYPE 4   /* a sample type or layout this reader leaves to NumPy / PIL */
 #define FX_IO_ESHAPE 5   /* not 2-D with at least 3 columns */
-#define FX_IO_EROWS 6    /* 2-D float array with a row count other than `rows` (rows_found tells it) */
+#define FX_IO_EROWS 6    /* readable, but not of the batch's common size (the found size is reported) */
 
 /*
  * Batch form of load_sample, src/features/extract_3d_pca_features.py:48-56
@@ -197,6 +197,21 @@ int fx_read_npy_points_f32(const char *const *paths, int64_t n, int64_t rows,
  */
 int fx_write_npy_rows_f32(const char *const *paths, int64_t n, const float *data,
                           int64_t row_len, int32_t *status, int n_threads);
+
+/*
+ * Batch form of load_image, src/features/extract_2d_hu.py:84-98 (PIL branch:
+ * Image.open(path).convert("L")): decodes n PNG files of H x W pixels into
+ * out[i] (n x H x W uint8, host memory).  Handles what a renderer writes:
+ * 8 bits per sample, gray / gray+alpha / RGB / RGBA, not interlaced, no tRNS;
+ * gray = (R*19595 + G*38470 + B*7471 + 0x8000) >> 16 as PIL, alpha ignored.
+ * Any other file (other size: FX_IO_EROWS with found_hw[2i], found_hw[2i+1] =
+ * its height and width; palette, 16 bit, interlaced, damaged, not a PNG) gets
+ * a status and is left for the caller to hand to PIL, which decides what is an
+ * error.
+ */
+int fx_decode_png_gray_u8(const char *const *paths, int64_t n, int H, int W,
+                          uint8_t *out, int32_t *status, int32_t *found_hw,
+                          int n_threads);
 
 /*
  * Synthetic inputs for benchmarks and parity tests (no reference counterpart:

@@ -100,3 +100,41 @@ def test_pca_directory_run_and_merge(gpu, tmp_path, oracle):
     m = pd.read_csv(tmp_path / "features.csv").set_index("id")
     assert len(m) == 6 and m.loc["cloud_4", "hu1_mean"] == 0 and m.loc["cloud_2", "hu1_mean"] == 2.0
     assert m.loc["cloud_1", "lambda1"] == pytest.approx(df.loc["cloud_1", "lambda1"])
+
+
+def test_hu_directory_run_mixed_files(gpu, tmp_path, oracle, c_oracle, hu_panels):
+    """One sample whose views come as RGB PNG, RGBA PNG, palette PNG, JPEG and a
+    PNG of another size: native decoder and PIL side by side, rows in file-name
+    order, every view resized to the target like the reference does."""
+    from PIL import Image
+    hu = pkg("extract_2d_hu")
+    views, out, rep = tmp_path / "views", tmp_path / "2d_hu", tmp_path / "reports"
+    raw = hu_panels["raw_views"]
+    d = views / "tree_mixed"
+    d.mkdir(parents=True)
+    Image.fromarray(raw[0, 0]).convert("RGB").save(d / "view_01.png")
+    Image.fromarray(raw[0, 1]).convert("RGBA").save(d / "view_02.png")
+    Image.fromarray(raw[0, 2]).convert("P").save(d / "view_03.png")
+    Image.fromarray(raw[1, 0]).save(d / "view_04.jpg", quality=95)
+    Image.fromarray(raw[1, 1][:180, :200]).save(d / "view_05.png")
+    Image.fromarray(raw[1, 2]).save(d / "view_06.png")
+    d2 = views / "tree_plain"
+    d2.mkdir()
+    for v in range(3):
+        Image.fromarray(raw[2, v]).save(d2 / f"view_{v + 1:02d}.png")
+    for silhouette in (True, False):
+        argv = ["--views_dir", str(views), "--out_dir", str(out), "--reports_dir", str(rep), "--preprocess_crop",
+                "--expected_views", "3", "--overwrite"] + (["--use_silhouette"] if silhouette else [])
+        assert hu.main(argv) == 0
+        df = pd.read_csv(out / "hu_features_table.csv").set_index("id")
+        assert df.loc["tree_mixed", "note"] == "ok" and df.loc["tree_plain", "note"] == "ok"
+        for sid, folder in (("tree_mixed", d), ("tree_plain", d2)):
+            rows = []
+            for f in sorted(folder.iterdir()):
+                img = np.asarray(Image.open(f).convert("L"))
+                pre, mask = oracle.preprocess_image(img, 224, 0.05, "white", True)
+                rows.append(c_oracle.hu_batch((mask if silhouette else pre)[None])["hulog7"][0])
+            want = oracle.hu_groupstat(np.stack(rows))[0]
+            got = df.loc[sid, hu.HU_COLS[1:15]].to_numpy(dtype=np.float64).astype(np.float32)
+            np.testing.assert_allclose(got[:7], want[:7], rtol=2e-6)
+            np.testing.assert_allclose(got[7:], want[7:], rtol=1e-4, atol=1e-6)

@@ -291,3 +291,46 @@ def test_native_npy_batch_io(tmp_path):
         assert Path(outs[i]).read_bytes() == (tmp_path / "ref.npy").read_bytes()
         np.testing.assert_array_equal(np.load(outs[i], allow_pickle=False), vec[i])
     assert len(ing.write_rows_batch([], np.zeros((0, 17), np.float32), 4)) == 0
+
+
+def test_native_png_decode_equals_pil(tmp_path):
+    """fx_decode_png_gray_u8 against Image.open(path).convert("L"), and what it must leave to PIL."""
+    from PIL import Image
+    ing = pkg("ingest")
+    rng = np.random.default_rng(2)
+    H, W = 96, 130
+    paths, want = [], []
+    for i, mode in enumerate(["L", "RGB", "RGBA", "LA"] * 6):
+        ch = {"L": 1, "RGB": 3, "RGBA": 4, "LA": 2}[mode]
+        if i % 3 == 0:
+            a = rng.integers(0, 256, (H, W, ch), dtype=np.uint8)            # noise: every filter type shows up
+        else:
+            yy, xx = np.mgrid[0:H, 0:W]
+            a = np.stack([((yy * (c + 2) + xx * 3 + 7 * i) % 256).astype(np.uint8) for c in range(ch)], axis=-1)
+            a[20:60, 30:90] = 30 + i
+        p = tmp_path / f"v{i:02d}.png"
+        Image.fromarray(a[..., 0] if ch == 1 else a, mode=mode).save(p, optimize=bool(i % 5 == 0),
+                                                                    compress_level=(1, 6, 9)[i % 3])
+        paths.append(str(p))
+        want.append(np.asarray(Image.open(p).convert("L")))
+    out = np.zeros((len(paths), H, W), dtype=np.uint8)
+    status, found = ing.decode_png_batch(paths, H, W, out, 4)
+    assert (status == 0).all() and (found == [H, W]).all()
+    for i in range(len(paths)):
+        np.testing.assert_array_equal(out[i], want[i], err_msg=paths[i])
+
+    gray = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    Image.fromarray(gray).convert("P").save(tmp_path / "pal.png")
+    Image.fromarray(rng.integers(0, 65535, (H, W)).astype(np.uint16)).save(tmp_path / "i16.png")
+    Image.fromarray(gray[:50]).save(tmp_path / "small.png")
+    Image.fromarray(gray).save(tmp_path / "inter.png", interlace=True) if False else None
+    raw = bytearray(Path(paths[0]).read_bytes())
+    raw[len(raw) // 2] ^= 0xFF
+    (tmp_path / "bad.png").write_bytes(raw)
+    (tmp_path / "trunc.png").write_bytes(Path(paths[0]).read_bytes()[: len(raw) // 2])
+    Image.fromarray(gray).save(tmp_path / "x.jpg")
+    odd = [str(tmp_path / n) for n in ("pal.png", "i16.png", "small.png", "bad.png", "trunc.png", "x.jpg", "none.png")]
+    status, found = ing.decode_png_batch(odd, H, W, np.zeros((7, H, W), np.uint8), 2)
+    assert status.tolist() == [4, 4, 6, 3, 3, 3, 1]
+    assert found[2].tolist() == [50, W]
+    assert ing.image_size(paths[0]) == (H, W) and ing.image_size(tmp_path / "none.png") is None
