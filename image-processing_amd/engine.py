@@ -179,6 +179,58 @@ def pca_batch(points: torch.Tensor, offsets: Optional[torch.Tensor] = None, n_bi
     return res
 
 
+def center_scale(points: torch.Tensor, offsets, *, maxdist: bool = False) -> dict:
+    """Centred, unit-sphere-scaled float32 copy of B clouds stored back to back
+    ([total, 3] float32 or float64 on the device; `offsets` = B + 1 row
+    offsets on the host).  Returns {"points": f32 [total, 3], "centroid": f32
+    [B, 3]} and on request "maxdist" f64 [B]."""
+    import numpy as np
+    _require_cuda(points, "points")
+    if points.dim() != 2 or points.shape[1] != 3 or points.dtype not in (torch.float32, torch.float64) \
+            or not points.is_contiguous():
+        raise ValueError("points must be contiguous float32/float64 [total, 3]")
+    off = np.ascontiguousarray(offsets, dtype=np.int64)
+    if off.ndim != 1 or off.size < 1 or off[0] != 0 or off[-1] != points.shape[0]:
+        raise ValueError("offsets must start at 0 and end at the number of points")
+    B = off.size - 1
+    stream = _enter(points.device)
+    out = {"points": torch.empty((points.shape[0], 3), dtype=torch.float32, device=points.device),
+           "centroid": torch.empty((B, 3), dtype=torch.float32, device=points.device)}
+    if maxdist:
+        out["maxdist"] = torch.empty((B,), dtype=torch.float64, device=points.device)
+    if B:
+        _lib.call("fx_center_scale", points.data_ptr(), int(points.dtype == torch.float64), off.ctypes.data, B,
+                  out["points"].data_ptr(), out["centroid"].data_ptr(), _ptr(out.get("maxdist")), stream)
+    return out
+
+
+def fps(points: torch.Tensor, offsets, n_samples: int, start, *, gather: bool = True) -> dict:
+    """Farthest point sampling of B clouds stored back to back (float32
+    [total, 3] on the device, `offsets` and the per-cloud first index `start`
+    on the host; every cloud needs more than n_samples points).  Returns
+    {"idx": int64 [B, n_samples]} and, with gather, "sampled" f32 [B, n_samples, 3]."""
+    import numpy as np
+    _require_cuda(points, "points")
+    if points.dim() != 2 or points.shape[1] != 3 or points.dtype != torch.float32 or not points.is_contiguous():
+        raise ValueError("points must be contiguous float32 [total, 3]")
+    off = np.ascontiguousarray(offsets, dtype=np.int64)
+    st = np.ascontiguousarray(start, dtype=np.int64)
+    if off.ndim != 1 or off.size < 1 or off[0] != 0 or off[-1] != points.shape[0]:
+        raise ValueError("offsets must start at 0 and end at the number of points")
+    B = off.size - 1
+    if st.shape != (B,):
+        raise ValueError("start must hold one index per cloud")
+    stream = _enter(points.device)
+    n = int(n_samples)
+    out = {"idx": torch.empty((B, n), dtype=torch.int64, device=points.device)}
+    if gather:
+        out["sampled"] = torch.empty((B, n, 3), dtype=torch.float32, device=points.device)
+    if B:
+        _lib.call("fx_fps_f32", points.data_ptr(), off.ctypes.data, B, n, st.ctypes.data, out["idx"].data_ptr(),
+                  _ptr(out.get("sampled")), stream)
+    return out
+
+
 def synth_shapes(B: int, H: int, W: int, seed: int = 42, first_index: int = 0, device="cuda",
                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """B synthetic {0,255} shape images generated on the device."""

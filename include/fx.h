@@ -167,6 +167,35 @@ int fx_gray_fit_batch_u8(const uint8_t *d_img, int64_t B, int H, int W,
                          int resolution, int bg_value, uint8_t *d_out, void *stream);
 
 /*
+ * Point-cloud normalisation and farthest point sampling, the stage that
+ * produces the fixed-size sets fx_pca_batch_f32 reads.  B clouds stored back to
+ * back, cloud b = rows h_offsets[b] .. h_offsets[b+1] (HOST array of B + 1
+ * entries).  Both calls return after their work on `stream` has finished.
+ *
+ * fx_center_scale replaces center_and_scale, src/preprocessing/prepare_all.py
+ * :199-217: centroid = np.mean(points, axis=0) in float64 (rows added in
+ * order), points minus centroid divided by the largest np.linalg.norm (left
+ * undivided when that is 0), cast to float32.  d_pts is float32 (wide = 0) or
+ * float64 (wide = 1) [total, 3]; d_out float32 [total, 3]; d_centroid float32
+ * [B, 3]; d_maxdist (optional) float64 [B].  Bit-identical to NumPy.
+ *
+ * fx_fps_f32 replaces the sampling loop of farthest_point_sampling, :276-293,
+ * for clouds with more points than n_samples (the reference's other branch,
+ * tiling + RandomState.shuffle, stays with the caller, as does the draw of the
+ * start index): float64 distances sqrt((dx*dx + dy*dy) + dz*dz) to the points
+ * chosen so far, np.minimum, np.argmax with the first of equal maxima.
+ * h_start (HOST, [B]) is the first index of each cloud.  d_idx int64
+ * [B, n_samples]; d_sampled (optional) float32 [B, n_samples, 3] = the chosen
+ * points.  Indices equal NumPy's.
+ */
+int fx_center_scale(const void *d_pts, int wide, const int64_t *h_offsets,
+                    int64_t B, float *d_out, float *d_centroid, double *d_maxdist,
+                    void *stream);
+int fx_fps_f32(const float *d_pts, const int64_t *h_offsets, int64_t B,
+               int n_samples, const int64_t *h_start, int64_t *d_idx,
+               float *d_sampled, void *stream);
+
+/*
  * Host file I/O on native threads (no device work).  Per-file status codes:
  */
 #define FX_IO_OK 0

@@ -414,6 +414,47 @@ def preprocess_image(img: np.ndarray, resolution: int, crop_margin: float, bg_co
     return pad_and_resize(img[y0:y1, x0:x1], resolution, bg_color), mask
 
 
+# --------------------------------------------------------------------------
+# Point-cloud normalisation and farthest point sampling
+# (reference src/preprocessing/prepare_all.py:199-217, :250-293), restated.
+# Pinned by tests/golden/fps_golden.npz, which holds the reference's outputs.
+# --------------------------------------------------------------------------
+def center_and_scale(points: np.ndarray):
+    """(normalized float32 [M, 3], centroid float32 [3])."""
+    if points.size == 0:
+        return points.astype(np.float32), np.zeros(3, dtype=np.float32)
+    centroid = np.mean(points, axis=0)
+    centered = points - centroid
+    dists = np.linalg.norm(centered, axis=1)
+    max_dist = float(np.max(dists)) if dists.size > 0 else 0.0
+    scaled = centered if max_dist <= 0 else centered / max_dist
+    return scaled.astype(np.float32), centroid.astype(np.float32)
+
+
+def farthest_point_sampling(points: np.ndarray, n_samples: int, rng=None) -> np.ndarray:
+    """int64 [n_samples] indices; rng (a RandomState) draws the start index, or
+    shuffles the tiled indices when there are fewer points than samples."""
+    import math
+    M = points.shape[0]
+    if M == 0 or n_samples <= 0:
+        return np.array([], dtype=np.int64)
+    if n_samples >= M:
+        base = np.tile(np.arange(M, dtype=np.int64), int(math.ceil(n_samples / M)))[:n_samples]
+        if rng is not None:
+            rng.shuffle(base)
+        return base.astype(np.int64)
+    pts = points.astype(np.float64)
+    indices = np.zeros(n_samples, dtype=np.int64)
+    start = int(rng.randint(0, M)) if rng is not None else 0
+    indices[0] = start
+    dists = np.linalg.norm(pts - pts[start], axis=1)
+    for i in range(1, n_samples):
+        far_idx = int(np.argmax(dists))
+        indices[i] = far_idx
+        dists = np.minimum(dists, np.linalg.norm(pts - pts[far_idx], axis=1))
+    return indices
+
+
 def build_c_oracle(force: bool = False) -> Path:
     so = _HERE / "libfx_oracle.so"
     src = _HERE / "fx_oracle.c"

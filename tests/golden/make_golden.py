@@ -23,6 +23,11 @@ preprocess_golden.npz
     Outputs of the reference's preprocess_image / compute_otsu (no-OpenCV
     branch) on eight of those raw view panels, with and without cropping.
 
+fps_golden.npz
+    Inputs and outputs of the reference's center_and_scale and
+    farthest_point_sampling (src/preprocessing/prepare_all.py:199-217,
+    :250-293), imported from the reference checkout.
+
 hu_table_rows.csv
     The rows of data/features/features_table.csv (12-view mean/std of log-Hu
     and the PCA columns) for those ids, plus reports/hu_feature_stats.csv and
@@ -153,6 +158,40 @@ def make_preprocess(ref: Path) -> None:
     print(f"preprocess_golden.npz: {len(raws)} images x 2 settings")
 
 
+def make_fps(ref: Path) -> None:
+    """Outputs of the reference's own center_and_scale / farthest_point_sampling
+    (src/preprocessing/prepare_all.py) on seeded clouds: float32- and
+    float64-valued inputs, sizes either side of what the device keeps in
+    registers, with and without a RandomState, the tiling branch, duplicated
+    points (ties in argmax)."""
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, str(ref / "src" / "preprocessing"))
+    mod = importlib.import_module("prepare_all")
+    rng = np.random.default_rng(20251111)
+    out = {}
+    specs = [(50, 16, None, True), (700, 64, 7, True), (3000, 1024, 11, False), (3000, 1024, None, True),
+             (20000, 256, 3, True), (40, 64, 5, True), (40, 64, None, True), (512, 128, 1, True)]
+    for k, (M, n, seed, f32) in enumerate(specs):
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        pts = (rng.normal(size=(M, 3)) * np.exp(rng.uniform(-1, 2, size=3))) @ q.T + rng.normal(size=3) * 30
+        if k == 7:                       # every point twice, and a regular grid: equal distances
+            g = np.stack(np.meshgrid(np.arange(8.0), np.arange(8.0), np.arange(4.0), indexing="ij"), -1).reshape(-1, 3)
+            pts = np.concatenate([g, g], axis=0)
+        if f32:
+            pts = pts.astype(np.float32).astype(np.float64)
+        norm, cen = mod.center_and_scale(pts)
+        r = np.random.RandomState(seed) if seed is not None else None
+        idx = mod.farthest_point_sampling(norm.astype(np.float32), n, rng=r)
+        out[f"pts_{k}"] = pts if not f32 else pts.astype(np.float32)
+        out[f"norm_{k}"] = norm
+        out[f"cen_{k}"] = cen
+        out[f"idx_{k}"] = idx
+        out[f"meta_{k}"] = np.array([n, -1 if seed is None else seed], dtype=np.int64)
+    out["n_cases"] = np.array(len(specs))
+    np.savez_compressed(HERE / "fps_golden.npz", **out)
+    print(f"fps_golden.npz: {len(specs)} cases")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default=os.environ.get("FX_REFERENCE", "/root/reference"))
@@ -160,3 +199,4 @@ if __name__ == "__main__":
     make_pca(Path(a.reference))
     make_hu(Path(a.reference))
     make_preprocess(Path(a.reference))
+    make_fps(Path(a.reference))

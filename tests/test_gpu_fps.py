@@ -1,0 +1,108 @@
+"""Point-cloud normalisation and farthest point sampling on the device against
+the reference's outputs (golden) and the oracle's NumPy restatement: bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, pkg
+
+pytestmark = pytest.mark.gpu
+
+
+def cloud(rng, M, f32=True, shift=30.0):
+    q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    p = (rng.normal(size=(M, 3)) * np.exp(rng.uniform(-1, 2, size=3))) @ q.T + rng.normal(size=3) * shift
+    return p.astype(np.float32) if f32 else p
+
+
+def test_golden_of_the_reference(gpu):
+    prep = pkg("prepare_all")
+    g = np.load(GOLDEN / "fps_golden.npz")
+    for k in range(int(g["n_cases"])):
+        pts = g[f"pts_{k}"]
+        n, seed = (int(v) for v in g[f"meta_{k}"])
+        norm, cen = prep.center_and_scale(pts.astype(np.float64))
+        np.testing.assert_array_equal(norm, g[f"norm_{k}"], err_msg=f"case {k}")
+        np.testing.assert_array_equal(cen, g[f"cen_{k}"])
+        assert norm.dtype == np.float32 and cen.dtype == np.float32
+        rng = np.random.RandomState(seed) if seed >= 0 else None
+        idx = prep.farthest_point_sampling(norm, n, rng)
+        assert idx.dtype == np.int64
+        np.testing.assert_array_equal(idx, g[f"idx_{k}"], err_msg=f"case {k}")
+
+
+def test_center_and_scale_batch_against_oracle(gpu, oracle):
+    prep = pkg("prepare_all")
+    rng = np.random.default_rng(5)
+    clouds = [cloud(rng, M, f32) for M, f32 in ((1, True), (2, True), (3, False), (257, True), (5000, False),
+                                                (70000, True), (1000, False))]
+    clouds.append(np.tile(np.array([[1.5, -2.0, 0.25]]), (40, 1)))        # all points equal: nothing to scale
+    clouds.append(np.zeros((0, 3)))                                        # empty: the reference's early return
+    clouds.append(cloud(rng, 4096, False, shift=1e6))                      # far from the origin
+    # read_pointcloud hands float64 to center_and_scale whatever the file held
+    clouds = [c.astype(np.float64) for c in clouds]
+    got = prep.center_and_scale_batch(clouds)
+    for k, c in enumerate(clouds):
+        want = oracle.center_and_scale(c)
+        np.testing.assert_array_equal(got[k][0], want[0], err_msg=f"cloud {k}")
+        np.testing.assert_array_equal(got[k][1], want[1], err_msg=f"cloud {k}")
+
+
+@pytest.mark.parametrize("M,n", [(20, 8), (1025, 1024), (3000, 1024), (16384, 512), (16385, 300), (60000, 1024)])
+def test_fps_against_oracle(gpu, oracle, M, n):
+    prep = pkg("prepare_all")
+    rng = np.random.default_rng(M + n)
+    pts = oracle.center_and_scale(cloud(rng, M).astype(np.float64))[0]
+    for seed in (None, 123):
+        r1 = np.random.RandomState(seed) if seed is not None else None
+        r2 = np.random.RandomState(seed) if seed is not None else None
+        got = prep.farthest_point_sampling(pts, n, r1)
+        want = oracle.farthest_point_sampling(pts, n, r2)
+        np.testing.assert_array_equal(got, want)
+        if seed is not None:                       # the caller's random stream advanced exactly as in the reference
+            assert r1.randint(0, 1 << 30) == r2.randint(0, 1 << 30)
+
+
+def test_fps_ties_and_host_branches(gpu, oracle):
+    prep = pkg("prepare_all")
+    g = np.stack(np.meshgrid(np.arange(16.0), np.arange(16.0), np.arange(8.0), indexing="ij"), -1).reshape(-1, 3)
+    grid = np.concatenate([g, g[::-1]], axis=0).astype(np.float32)        # every point twice: equal maxima throughout
+    np.testing.assert_array_equal(prep.farthest_point_sampling(grid, 600), oracle.farthest_point_sampling(grid, 600))
+    small = cloud(np.random.default_rng(1), 10)
+    for n, seed in ((10, 3), (25, 3), (25, None), (0, 3)):
+        r1 = np.random.RandomState(seed) if seed is not None else None
+        r2 = np.random.RandomState(seed) if seed is not None else None
+        np.testing.assert_array_equal(prep.farthest_point_sampling(small, n, r1),
+                                      oracle.farthest_point_sampling(small, n, r2))
+    assert prep.farthest_point_sampling(np.zeros((0, 3), np.float32), 5).size == 0
+    with pytest.raises(ValueError, match="float32"):
+        prep.farthest_point_sampling(np.random.default_rng(0).normal(size=(100, 3)), 10)
+
+
+def test_normalize_and_sample_pipeline(gpu, oracle):
+    """center_and_scale -> FPS on the float32 result -> gather, as the reference's per-file pipeline."""
+    prep = pkg("prepare_all")
+    rng = np.random.default_rng(9)
+    clouds = [cloud(rng, M, f32=False) for M in (5000, 300, 1500, 20000, 1024)]
+    seeds = [5, 6, None, 8, 9]
+    got = prep.normalize_and_sample(clouds, 1024, [np.random.RandomState(s) if s is not None else None for s in seeds])
+    for k, c in enumerate(clouds):
+        norm, cen = oracle.center_and_scale(c)
+        idx = oracle.farthest_point_sampling(norm.astype(np.float32), 1024,
+                                             np.random.RandomState(seeds[k]) if seeds[k] is not None else None)
+        np.testing.assert_array_equal(got[k][2], idx, err_msg=f"cloud {k}")
+        np.testing.assert_array_equal(got[k][0], norm[idx].astype(np.float32))
+        np.testing.assert_array_equal(got[k][1], cen)
+
+
+def test_fps_rejects_bad_arguments(gpu):
+    eng, lib = pkg("engine"), pkg("_lib")
+    pts = torch.zeros((100, 3), dtype=torch.float32, device=gpu)
+    with pytest.raises(lib.FxError, match="needs more than that many"):
+        eng.fps(pts, [0, 100], 100, [0])
+    with pytest.raises(lib.FxError, match="start index"):
+        eng.fps(pts, [0, 100], 10, [100])
+    with pytest.raises(ValueError):
+        eng.fps(pts, [0, 50], 10, [0])
+    with pytest.raises(ValueError):
+        eng.center_scale(pts.to(torch.float16), [0, 100])

@@ -155,3 +155,18 @@ def test_pil_gaussian_blur_written_out(oracle):
         img = rng.integers(0, 256, shape, dtype=np.uint8)
         ref = np.asarray(Image.fromarray(img).filter(ImageFilter.GaussianBlur(radius=1)))
         np.testing.assert_array_equal(oracle.pil_gaussian_blur_r1(img), ref)
+
+
+# ------------------------------------------------------------ point-cloud preparation
+def test_fps_restatement_equals_reference_outputs(oracle):
+    """fps_golden.npz holds outputs of the reference's center_and_scale and
+    farthest_point_sampling; the restatements must reproduce them bit for bit."""
+    g = np.load(GOLDEN / "fps_golden.npz")
+    for k in range(int(g["n_cases"])):
+        pts = g[f"pts_{k}"].astype(np.float64)
+        n, seed = (int(v) for v in g[f"meta_{k}"])
+        norm, cen = oracle.center_and_scale(pts)
+        np.testing.assert_array_equal(norm, g[f"norm_{k}"])
+        np.testing.assert_array_equal(cen, g[f"cen_{k}"])
+        rng = np.random.RandomState(seed) if seed >= 0 else None
+        np.testing.assert_array_equal(oracle.farthest_point_sampling(norm, n, rng), g[f"idx_{k}"])
