@@ -15,8 +15,6 @@ namespace {
 
 constexpr int FPS_THREADS = 1024;
 constexpr int FPS_WAVES = FPS_THREADS / FX_WAVE;
-constexpr int FPS_PPT = 16;                        // points per thread held in registers
-constexpr int FPS_REG_MAX = FPS_THREADS * FPS_PPT;  // 16384
 
 struct CloudArgs {
     const void *pts;         // [total][3] float32 or float64
@@ -36,31 +34,73 @@ __device__ __forceinline__ double cloud_load(const CloudArgs &A, int64_t i, int 
     return A.wide ? ((const double *)A.pts)[i * 3 + c] : (double)((const float *)A.pts)[i * 3 + c];
 }
 
-// One lane per (cloud, column): the rows are added in order, as NumPy does.
+// Column sums of a cloud with the rows added in order, as NumPy does.  A wave
+// per cloud: all lanes stream the cloud through LDS in tiles (coalesced loads,
+// the next tile in flight), lanes 0..2 each add one column's values one after
+// the other.
+constexpr int SUM_TILE = 128;            // rows per tile
+constexpr int SUM_TILE3 = SUM_TILE * 3;  // values per tile
+constexpr int SUM_VPL = SUM_TILE3 / FX_WAVE;
+
 __global__ __launch_bounds__(FX_BLOCK) void cloud_colsum_kernel(CloudArgs A)
 {
-    const int64_t g = (int64_t)blockIdx.x * FX_BLOCK + threadIdx.x;
-    if (g >= A.B * 3)
+    __shared__ double s_tile[FX_WAVES_PER_BLOCK][2][SUM_TILE3];
+    const int lane = fx_lane(), wave = fx_wave();
+    const int64_t b = (int64_t)blockIdx.x * FX_WAVES_PER_BLOCK + wave;
+    if (b >= A.B)
         return;
-    const int64_t b = g / 3;
-    const int c = (int)(g - b * 3);
     const int64_t lo = A.offsets[b], hi = A.offsets[b + 1];
+    const int64_t m = hi - lo, n3 = m * 3;
+    const int64_t base = lo * 3;
+    auto load = [&](int64_t tile, double (&v)[SUM_VPL]) {
+#pragma unroll
+        for (int j = 0; j < SUM_VPL; j++) {
+            const int64_t e = tile * SUM_TILE3 + j * FX_WAVE + lane;
+            v[j] = e < n3 ? (A.wide ? ((const double *)A.pts)[base + e] : (double)((const float *)A.pts)[base + e]) : 0.0;
+        }
+    };
+    auto store = [&](int buf, const double (&v)[SUM_VPL]) {
+#pragma unroll
+        for (int j = 0; j < SUM_VPL; j++)
+            s_tile[wave][buf][j * FX_WAVE + lane] = v[j];
+    };
+    const int64_t tiles = (m + SUM_TILE - 1) / SUM_TILE;
+    double v[SUM_VPL];
     double s = 0.0;
-    int64_t i = lo;
-    for (; i + 8 <= hi; i += 8) {
-        double v[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++)
-            v[k] = cloud_load(A, i + k, c);
-#pragma unroll
-        for (int k = 0; k < 8; k++)
-            s += v[k];
+    if (tiles > 0) {
+        load(0, v);
+        store(0, v);
     }
-    for (; i < hi; i++)
-        s += cloud_load(A, i, c);
-    const int64_t m = hi - lo;
-    A.centroid[g] = m > 0 ? s / (double)m : 0.0;
-    if (c == 0)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int64_t k = 0; k < tiles; k++) {
+        if (k + 1 < tiles)
+            load(k + 1, v);
+        if (lane < 3) {
+            const int64_t left = m - k * SUM_TILE;
+            const int rows = (int)(left < SUM_TILE ? left : SUM_TILE);
+            const double *p = &s_tile[wave][k & 1][lane];
+            int r = 0;
+            for (; r + 16 <= rows; r += 16) {
+                double w[16];
+#pragma unroll
+                for (int j = 0; j < 16; j++)
+                    w[j] = p[(r + j) * 3];
+#pragma unroll
+                for (int j = 0; j < 16; j++)
+                    s += w[j];
+            }
+            for (; r < rows; r++)
+                s += p[r * 3];
+        }
+        if (k + 1 < tiles)
+            store((int)((k + 1) & 1), v);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane < 3)
+        A.centroid[b * 3 + lane] = m > 0 ? s / (double)m : 0.0;
+    if (lane == 0)
         A.maxbits[b] = 0ull;
 }
 
@@ -87,8 +127,17 @@ __global__ __launch_bounds__(FX_BLOCK) void cloud_maxnorm_kernel(CloudArgs A)
     const double x = cloud_load(A, i, 0) - A.centroid[b * 3 + 0];
     const double y = cloud_load(A, i, 1) - A.centroid[b * 3 + 1];
     const double z = cloud_load(A, i, 2) - A.centroid[b * 3 + 2];
-    const double d = sqrt((x * x + y * y) + z * z);
-    atomicMax(&A.maxbits[b], (unsigned long long)__double_as_longlong(d));
+    double d = sqrt((x * x + y * y) + z * z);
+    // one atomic per wave when the whole wave lies in one cloud (the usual case)
+    const int64_t b0 = __shfl(b, 0, FX_WAVE);
+    const bool full = __ballot(1) == ~0ull;
+    if (full && __all(b == b0)) {
+        d = fx_wave_max_f64(d);
+        if (fx_lane() == 0)
+            atomicMax(&A.maxbits[b], (unsigned long long)__double_as_longlong(d));
+    } else {
+        atomicMax(&A.maxbits[b], (unsigned long long)__double_as_longlong(d));
+    }
 }
 
 __global__ __launch_bounds__(FX_BLOCK) void cloud_scale_kernel(CloudArgs A)
@@ -129,9 +178,10 @@ __device__ __forceinline__ bool fps_may_lower(double d2, double dist)
     return !(d2 > dist * dist * (1.0 + 0x1p-50));
 }
 
-// A block per cloud.  REG: the cloud has at most FPS_REG_MAX points; a thread
-// keeps its points and their distances to the chosen set in registers.
-template <bool REG>
+// A block per cloud.  PPT > 0: the cloud has at most FPS_THREADS * PPT points
+// and a thread keeps its points and their distances to the chosen set in
+// registers; PPT == 0: any size, distances in scratch.
+template <int PPT>
 __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs A)
 {
     __shared__ double s_best[2][FPS_WAVES];
@@ -145,11 +195,12 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs A)
     int64_t *out_idx = A.idx + (int64_t)b * A.n_samples;
     float *out_pts = A.sampled ? A.sampled + (int64_t)b * A.n_samples * 3 : nullptr;
 
-    float px[REG ? FPS_PPT : 1], py[REG ? FPS_PPT : 1], pz[REG ? FPS_PPT : 1];
-    double dist[REG ? FPS_PPT : 1];
+    constexpr bool REG = PPT > 0;
+    float px[REG ? PPT : 1], py[REG ? PPT : 1], pz[REG ? PPT : 1];
+    double dist[REG ? PPT : 1];
     if (REG) {
 #pragma unroll
-        for (int k = 0; k < FPS_PPT; k++) {
+        for (int k = 0; k < PPT; k++) {
             const int i = t + k * FPS_THREADS;
             px[k] = i < m ? P[i * 3 + 0] : 0.f;
             py[k] = i < m ? P[i * 3 + 1] : 0.f;
@@ -176,7 +227,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs A)
         int bi = 0x7fffffff;
         if (REG) {
 #pragma unroll
-            for (int k = 0; k < FPS_PPT; k++) {
+            for (int k = 0; k < PPT; k++) {
                 const int i = t + k * FPS_THREADS;
                 const double dx = (double)px[k] - cx, dy = (double)py[k] - cy, dz = (double)pz[k] - cz;
                 const double d2 = (dx * dx + dy * dy) + dz * dz;
@@ -279,8 +330,8 @@ extern "C" int fx_center_scale(const void *d_pts, int wide, const int64_t *h_off
     A.total = total;
     FX_HIP_CHECK(hipMemcpyAsync(base, h_offsets, (size_t)(B + 1) * sizeof(int64_t), hipMemcpyHostToDevice, stream));
     FxProfileScope prof(stream);
-    hipLaunchKernelGGL(cloud_colsum_kernel, dim3((unsigned)((B * 3 + FX_BLOCK - 1) / FX_BLOCK)), dim3(FX_BLOCK), 0,
-                       stream, A);
+    hipLaunchKernelGGL(cloud_colsum_kernel, dim3((unsigned)((B + FX_WAVES_PER_BLOCK - 1) / FX_WAVES_PER_BLOCK)),
+                       dim3(FX_BLOCK), 0, stream, A);
     if (total > 0)
         hipLaunchKernelGGL(cloud_maxnorm_kernel, dim3((unsigned)((total + FX_BLOCK - 1) / FX_BLOCK)), dim3(FX_BLOCK),
                            0, stream, A);
@@ -303,7 +354,8 @@ extern "C" int fx_fps_f32(const float *d_pts, const int64_t *h_offsets, int64_t 
     FX_REQUIRE(d_pts && h_offsets && h_start && d_idx, "fx_fps_f32: null pointer");
     FX_REQUIRE(n_samples >= 1, "fx_fps_f32: n_samples = %d", n_samples);
     FX_REQUIRE(h_offsets[0] == 0, "fx_fps_f32: offsets[0] = %lld", (long long)h_offsets[0]);
-    std::vector<int32_t> small, large;
+    // size classes: 1, 2, 4, 8, 16 points per thread in registers, then the scratch path
+    std::vector<int32_t> cls[6];
     for (int64_t b = 0; b < B; b++) {
         const int64_t m = h_offsets[b + 1] - h_offsets[b];
         FX_REQUIRE(m > n_samples && m < (1ll << 31) / 3,
@@ -311,18 +363,22 @@ extern "C" int fx_fps_f32(const float *d_pts, const int64_t *h_offsets, int64_t 
                    (long long)b, (long long)m, n_samples);
         FX_REQUIRE(h_start[b] >= 0 && h_start[b] < m, "fx_fps_f32: start index %lld of cloud %lld outside 0..%lld",
                    (long long)h_start[b], (long long)b, (long long)m - 1);
-        (m <= FPS_REG_MAX ? small : large).push_back((int32_t)b);
+        int c = 0;
+        while (c < 5 && m > (int64_t)FPS_THREADS << c)
+            c++;
+        cls[c].push_back((int32_t)b);
     }
     const int64_t total = h_offsets[B];
     const size_t off_bytes = fps_align((size_t)(B + 1) * sizeof(int64_t));
     const size_t start_bytes = fps_align((size_t)B * sizeof(int64_t));
     const size_t ids_bytes = fps_align((size_t)B * sizeof(int32_t));
-    const size_t dist_bytes = large.empty() ? 0 : fps_align((size_t)total * sizeof(double));
+    const size_t dist_bytes = cls[5].empty() ? 0 : fps_align((size_t)total * sizeof(double));
     unsigned char *base = (unsigned char *)fx_scratch(off_bytes + start_bytes + ids_bytes + dist_bytes, 5);
     if (!base)
         return FX_ENOMEM;
-    std::vector<int32_t> ids(small);
-    ids.insert(ids.end(), large.begin(), large.end());
+    std::vector<int32_t> ids;
+    for (int c = 0; c < 6; c++)
+        ids.insert(ids.end(), cls[c].begin(), cls[c].end());
     FX_HIP_CHECK(hipMemcpyAsync(base, h_offsets, (size_t)(B + 1) * sizeof(int64_t), hipMemcpyHostToDevice, stream));
     FX_HIP_CHECK(hipMemcpyAsync(base + off_bytes, h_start, (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice, stream));
     FX_HIP_CHECK(hipMemcpyAsync(base + off_bytes + start_bytes, ids.data(), (size_t)B * sizeof(int32_t),
@@ -336,13 +392,22 @@ extern "C" int fx_fps_f32(const float *d_pts, const int64_t *h_offsets, int64_t 
     A.sampled = d_sampled;
     A.dist = (double *)(base + off_bytes + start_bytes + ids_bytes);
     FxProfileScope prof(stream);
-    if (!small.empty()) {
-        A.ids = (const int32_t *)(base + off_bytes + start_bytes);
-        hipLaunchKernelGGL(fps_kernel<true>, dim3((unsigned)small.size()), dim3(FPS_THREADS), 0, stream, A);
-    }
-    if (!large.empty()) {
-        A.ids = (const int32_t *)(base + off_bytes + start_bytes) + small.size();
-        hipLaunchKernelGGL(fps_kernel<false>, dim3((unsigned)large.size()), dim3(FPS_THREADS), 0, stream, A);
+    const int32_t *d_ids = (const int32_t *)(base + off_bytes + start_bytes);
+    size_t at = 0;
+    for (int c = 0; c < 6; c++) {
+        if (cls[c].empty())
+            continue;
+        A.ids = d_ids + at;
+        at += cls[c].size();
+        const dim3 grid((unsigned)cls[c].size()), block(FPS_THREADS);
+        switch (c) {
+        case 0: hipLaunchKernelGGL(fps_kernel<1>, grid, block, 0, stream, A); break;
+        case 1: hipLaunchKernelGGL(fps_kernel<2>, grid, block, 0, stream, A); break;
+        case 2: hipLaunchKernelGGL(fps_kernel<4>, grid, block, 0, stream, A); break;
+        case 3: hipLaunchKernelGGL(fps_kernel<8>, grid, block, 0, stream, A); break;
+        case 4: hipLaunchKernelGGL(fps_kernel<16>, grid, block, 0, stream, A); break;
+        default: hipLaunchKernelGGL(fps_kernel<0>, grid, block, 0, stream, A); break;
+        }
     }
     FX_HIP_CHECK(hipGetLastError());
     // the host vectors staged above go out of scope with this call

@@ -52,12 +52,31 @@ def time_sil(B, H, W, res, reps=5):
     ms.sort(); med = ms[len(ms)//2]
     return med, B*H*W/med/1e6
 
+def time_fps(B, M, n, reps=3):
+    import numpy as np
+    pts = eng.synth_points(B, M, seed=42, device=dev).reshape(B * M, 3).contiguous()
+    off = np.arange(B + 1, dtype=np.int64) * M
+    start = np.zeros(B, dtype=np.int64)
+    eng.center_scale(pts, off); eng.fps(pts, off, n, start)
+    torch.cuda.synchronize()
+    eng.profile(True); a = []; b = []
+    for _ in range(reps):
+        r = eng.center_scale(pts, off); a.append(eng.profile_last_ms())
+        eng.fps(r["points"], off, n, start); b.append(eng.profile_last_ms())
+    eng.profile(False)
+    a.sort(); b.sort()
+    return a[len(a)//2], b[len(b)//2]
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "hu"
     if what == "hu":
         for (B,H,W,c) in [(30000,512,512,False),(30000,512,512,True),(100000,256,256,False),(100000,256,256,True)]:
             ms, gbps = time_hu(B,H,W,c)
             print(f"hu B={B} {H}x{W} contour={c} dbg={os.environ.get('FX_DBG','0')}: {ms:.3f} ms  {gbps:.0f} GB/s", flush=True)
+    elif what == "fps":
+        for (B,M,n) in [(4000,2048,1024),(2000,8192,1024),(512,16384,1024),(64,100000,1024)]:
+            cs, fp = time_fps(B,M,n)
+            print(f"fps B={B} M={M} n={n}: center_scale {cs:.3f} ms ({B*M*12/cs/1e6:.0f} GB/s)  fps {fp:.3f} ms  {B/fp*1e3:.0f} clouds/s  {B*M*n/fp/1e6:.1f} G point-updates/s", flush=True)
     elif what == "sil1":
         ms, gbps = time_sil(20000, 224, 224, 224, reps=3)
         print(f"sil B=20000 224x224->224: {ms:.3f} ms  {gbps:.0f} GB/s", flush=True)
