@@ -104,9 +104,46 @@ struct Tot64 {
     __device__ __forceinline__ void clear() { t00 = t10 = t20 = t30 = t01 = t11 = t21 = t02 = t12 = t03 = 0; }
 };
 
-template <int MODE>
+// Power sums over the set bits of one byte of a 16-pixel foreground mask, for
+// the kernels whose weights are 0/1: entry [m] for the low byte (pixels 0..7),
+// entry [256 + m] for the high byte (pixels 8..15).  x = count | sum i << 5 |
+// sum i^2 << 12 (fields wide enough for the sum of a low and a high entry),
+// y = sum i^3.
+struct BandTabEntry {
+    uint32_t x, y;
+};
+struct BandTab {
+    BandTabEntry e[512];
+};
+constexpr BandTab make_band_tab()
+{
+    BandTab t{};
+    for (int half = 0; half < 2; half++) {
+        for (int m = 0; m < 256; m++) {
+            uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+            for (int k = 0; k < 8; k++) {
+                if (m & (1 << k)) {
+                    const uint32_t i = (uint32_t)(8 * half + k);
+                    s0 += 1;
+                    s1 += i;
+                    s2 += i * i;
+                    s3 += i * i * i;
+                }
+            }
+            t.e[half * 256 + m].x = s0 | (s1 << 5) | (s2 << 12);
+            t.e[half * 256 + m].y = s3;
+        }
+    }
+    return t;
+}
+__device__ const BandTab g_band_tab = make_band_tab();
+constexpr int BAND_TAB_BYTES = (int)sizeof(BandTab);  // 4 KiB
+
+// TAB: the moment sums of a 0/1-weighted chunk come from two lookups in `tab`
+// (an LDS copy of g_band_tab) instead of twenty dot products.
+template <int MODE, bool TAB = false>
 __device__ __forceinline__ void chunk_sums(const uint4 &v, uint32_t kthr, uint32_t j, Acc32 &a,
-                                           uint32_t &bits16)
+                                           uint32_t &bits16, const BandTabEntry *tab = nullptr)
 {
     uint32_t w[4] = {v.x, v.y, v.z, v.w};
     uint32_t src[4];
@@ -126,16 +163,26 @@ __device__ __forceinline__ void chunk_sums(const uint4 &v, uint32_t kthr, uint32
     const uint32_t hi8 = dot4(fg[3], 0x80402010u, dot4(fg[2], 0x08040201u, 0u));
     bits16 = lo8 | (hi8 << 8);
 
-    uint32_t s0 = 0, s1 = 0, s2 = 0, s3l = 0, s3h = 0;
+    uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    if (TAB && MODE != MODE_GRAY) {
+        const BandTabEntry L = tab[lo8], U = tab[256 + hi8];
+        const uint32_t packed = L.x + U.x;
+        s0 = packed & 31u;
+        s1 = (packed >> 5) & 127u;
+        s2 = packed >> 12;
+        s3 = L.y + U.y;
+    } else {
+        uint32_t s3l = 0, s3h = 0;
 #pragma unroll
-    for (int d = 0; d < 4; d++) {
-        s0 = dot4(src[d], 0x01010101u, s0);
-        s1 = dot4(src[d], K1(d), s1);
-        s2 = dot4(src[d], K2(d), s2);
-        s3l = dot4(src[d], K3L(d), s3l);
-        s3h = dot4(src[d], K3H(d), s3h);
+        for (int d = 0; d < 4; d++) {
+            s0 = dot4(src[d], 0x01010101u, s0);
+            s1 = dot4(src[d], K1(d), s1);
+            s2 = dot4(src[d], K2(d), s2);
+            s3l = dot4(src[d], K3L(d), s3l);
+            s3h = dot4(src[d], K3H(d), s3h);
+        }
+        s3 = s3l + (s3h << 8);
     }
-    uint32_t s3 = s3l + (s3h << 8);
     uint32_t j2 = j * j, j3 = j2 * j;  // j < 128, wave-uniform
     a.a00 += s0;
     a.a10 += s1;
@@ -646,6 +693,17 @@ __global__ __launch_bounds__(FX_BLOCK, FX_BAND_WAVES) void hu_band_kernel(HuArgs
     }
     const int cpr = A.cpr, hb = A.hb;
 
+    // 0/1 weights: the moment sums of a chunk are looked up by its mask bytes
+    constexpr bool TAB = MODE != MODE_GRAY;
+    const BandTabEntry *tab = reinterpret_cast<const BandTabEntry *>(lds_raw + BAND_LDS_WAVE + FX_WAVES_PER_BLOCK * wave_bytes);
+    if (TAB) {
+        uint2 *dst = reinterpret_cast<uint2 *>(lds_raw + BAND_LDS_WAVE + FX_WAVES_PER_BLOCK * wave_bytes);
+        const uint2 *srct = reinterpret_cast<const uint2 *>(g_band_tab.e);
+        dst[t] = srct[t];
+        dst[t + FX_BLOCK] = srct[t + FX_BLOCK];
+        __syncthreads();
+    }
+
     const int bl = lane / cpr, tx = lane - bl * cpr;
     const int x0 = tx * 16;
     const bool active = bl < A.bpw && x0 < W;
@@ -769,10 +827,10 @@ __global__ __launch_bounds__(FX_BLOCK, FX_BAND_WAVES) void hu_band_kernel(HuArgs
             uint4 v2 = load_chunk(r + 2);
             uint4 v3 = load_chunk(r + 3);
             uint32_t b0, b1, b2, b3;
-            chunk_sums<MODE>(v0, kthr, j, a, b0);
-            chunk_sums<MODE>(v1, kthr, j + 1, a, b1);
-            chunk_sums<MODE>(v2, kthr, j + 2, a, b2);
-            chunk_sums<MODE>(v3, kthr, j + 3, a, b3);
+            chunk_sums<MODE, TAB>(v0, kthr, j, a, b0, tab);
+            chunk_sums<MODE, TAB>(v1, kthr, j + 1, a, b1, tab);
+            chunk_sums<MODE, TAB>(v2, kthr, j + 2, a, b2, tab);
+            chunk_sums<MODE, TAB>(v3, kthr, j + 3, a, b3, tab);
             if (CONTOUR) {
                 if (r == 0) {
                     c_first = b0;
@@ -1377,7 +1435,7 @@ extern "C" int fx_hu_batch_u8(const uint8_t *d_img, int64_t B, int H, int W, int
         int rc;
         {
             FxProfileScope prof(s);
-            rc = launch_band(A, G, mode, false, aligned && (W % 16 == 0), (size_t)BAND_LDS_WAVE + (size_t)FX_WAVES_PER_BLOCK * A.wave_lds, s);
+            rc = launch_band(A, G, mode, false, aligned && (W % 16 == 0), (size_t)BAND_LDS_WAVE + (size_t)FX_WAVES_PER_BLOCK * A.wave_lds + BAND_TAB_BYTES, s);
         }
         if (rc != FX_OK)
             return rc;
@@ -1415,7 +1473,7 @@ extern "C" int fx_hu_batch_u8(const uint8_t *d_img, int64_t B, int H, int W, int
         FX_HIP_CHECK(hipMemsetAsync(G.redo_count, 0, 16, s));
 
     A.wave_lds = contour && A.qcap > BAND_SLAB_BYTES ? A.qcap : BAND_SLAB_BYTES;  // qcap / 4 entries of 4 bytes
-    const size_t band_lds = (size_t)BAND_LDS_WAVE + (size_t)FX_WAVES_PER_BLOCK * A.wave_lds;
+    const size_t band_lds = (size_t)BAND_LDS_WAVE + (size_t)FX_WAVES_PER_BLOCK * A.wave_lds + BAND_TAB_BYTES;
     int rc;
     {
         FxProfileScope prof(s);

@@ -69,7 +69,11 @@ def time_fps(B, M, n, reps=3):
 
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "hu"
-    if what == "hu":
+    if what == "hu1k":
+        for (B,H,W,c) in [(7500,1024,1024,False),(7500,1024,1024,True),(30000,512,512,True),(60000,512,256,True)]:
+            ms, gbps = time_hu(B,H,W,c)
+            print(f"hu B={B} {H}x{W} contour={c}: {ms:.3f} ms  {gbps:.0f} GB/s", flush=True)
+    elif what == "hu":
         for (B,H,W,c) in [(30000,512,512,False),(30000,512,512,True),(100000,256,256,False),(100000,256,256,True)]:
             ms, gbps = time_hu(B,H,W,c)
             print(f"hu B={B} {H}x{W} contour={c} dbg={os.environ.get('FX_DBG','0')}: {ms:.3f} ms  {gbps:.0f} GB/s", flush=True)
