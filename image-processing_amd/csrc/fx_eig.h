@@ -43,39 +43,32 @@ __device__ __forceinline__ void fx_jacobi_rotate(double &app, double &aqq, doubl
     }
 }
 
-// 1/x and 1/sqrt(x) from the hardware estimate plus two Newton steps: within a
-// couple of ulps, at a fraction of the IEEE division / square-root sequences.
-__device__ __forceinline__ double fx_rcp_nr(double x)
+// One Newton step on the hardware estimates (about 26 bits): full double
+// precision up to an ulp or two.
+__device__ __forceinline__ double fx_rcp_n1(double x)
 {
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma(r, fma(-x, r, 1.0), r);
-    r = fma(r, fma(-x, r, 1.0), r);
-    return r;
+    const double r = __builtin_amdgcn_rcp(x);
+    return fma(r, fma(-x, r, 1.0), r);
 }
-__device__ __forceinline__ double fx_rsq_nr(double x)
+__device__ __forceinline__ double fx_rsq_n1(double x)
 {
-    double r = __builtin_amdgcn_rsq(x);
-    r = fma(r * 0.5, fma(-x * r, r, 1.0), r);
-    r = fma(r * 0.5, fma(-x * r, r, 1.0), r);
-    return r;
+    const double r = __builtin_amdgcn_rsq(x);
+    return fma(r * 0.5, fma(-x * r, r, 1.0), r);
 }
 
-// The same rotation with Newton-refined reciprocals.  A rotation only has to
-// be orthogonal to rounding level (c^2 + s^2 = 1 +- a few ulps) and to shrink
-// a_pq; the last bits of the angle do not matter to the converged result.
-__device__ __forceinline__ void fx_jacobi_rotate_fast(double &app, double &aqq, double &apq, double &arp,
-                                                      double &arq, double (&V)[3][3], int p, int q)
+__device__ __forceinline__ void fx_jacobi_rotate_n1(double &app, double &aqq, double &apq, double &arp,
+                                                    double &arq, double (&V)[3][3], int p, int q)
 {
     if (apq == 0.0)
         return;
     const double d = aqq - app;
     const double two = apq + apq;
     const double h2 = fma(d, d, two * two);
-    const double h = h2 * fx_rsq_nr(h2);
-    double t = two * fx_rcp_nr(fabs(d) + h);
+    const double h = h2 * fx_rsq_n1(h2);
+    double t = two * fx_rcp_n1(fabs(d) + h);
     if (d < 0.0)
         t = -t;
-    const double c = fx_rsq_nr(fma(t, t, 1.0));
+    const double c = fx_rsq_n1(fma(t, t, 1.0));  // c^2 + s^2 = 1 within 1e-15
     const double s = t * c;
     const double tap = t * apq;
     app = app - tap;
@@ -98,7 +91,10 @@ __device__ __forceinline__ void fx_jacobi_rotate_fast(double &app, double &aqq, 
 // sweeps.  A coordinate that is exactly uncoupled (its off-diagonal entries are
 // 0.0, e.g. z of a planar set) keeps its diagonal entry unchanged, so a planar
 // set gets an exact 0.0 eigenvalue as LAPACK's eigh returns for it.
-// FAST: Newton-refined reciprocals in the rotations and the matrix scaled to
+// FAST: reciprocals from the hardware estimate plus one Newton step in the
+// rotations (a rotation only has to be orthogonal to rounding level and to
+// shrink a_pq; the last bits of the angle do not matter to the converged
+// result) and the matrix scaled to
 // unit magnitude first (so that squares cannot leave the double range); used
 // where the solve sits on the critical path of a streaming kernel.
 template <bool FAST = false>
@@ -127,9 +123,9 @@ __device__ __forceinline__ void fx_eig3(double a00, double a01, double a02, doub
         if (off == 0.0 || off <= (FAST ? 1e-13 : 1e-19) * diag)
             break;
         if (FAST) {
-            fx_jacobi_rotate_fast(a00, a11, a01, a02, a12, V, 0, 1);
-            fx_jacobi_rotate_fast(a00, a22, a02, a01, a12, V, 0, 2);
-            fx_jacobi_rotate_fast(a11, a22, a12, a01, a02, V, 1, 2);
+            fx_jacobi_rotate_n1(a00, a11, a01, a02, a12, V, 0, 1);
+            fx_jacobi_rotate_n1(a00, a22, a02, a01, a12, V, 0, 2);
+            fx_jacobi_rotate_n1(a11, a22, a12, a01, a02, V, 1, 2);
         } else {
             fx_jacobi_rotate(a00, a11, a01, a02, a12, V, 0, 1);
             fx_jacobi_rotate(a00, a22, a02, a01, a12, V, 0, 2);
