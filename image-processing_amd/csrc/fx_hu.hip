@@ -51,6 +51,11 @@ struct HuArgs {
     const uint32_t *redo_count;
     const uint32_t *redo_list;
     int only_redo;  // mask kernel: work through redo_list instead of all B images
+    // row-band mode: the images are bands of taller images that start at row
+    // y_offset; the exact raw moments in the tall image's coordinates are
+    // written as three 48-bit limbs each instead of being finalised
+    int64_t *partial;  // [B][10][3] or null
+    int64_t y_offset;
 };
 
 constexpr int MODE_GRAY = 0;     // weight = pixel value
@@ -1047,7 +1052,7 @@ __global__ __launch_bounds__(FX_BLOCK) void hu_tile_combine_kernel(HuArgs A, Ban
     for (int tile = 0; tile < tiles; tile++) {
         const u64 *t = G.sums + (b * tiles + tile) * BAND_SUMS;
         const int tyi = tile / A.tiles_x, txi = tile - tyi * A.tiles_x;
-        const u128 X = (u128)(txi * TILE_W), Y = (u128)(tyi * TILE_H);
+        const u128 X = (u128)(txi * TILE_W), Y = (u128)(tyi * TILE_H) + (u128)(A.partial ? A.y_offset : 0);
         const u128 t00 = t[0], t10 = t[1], t01 = t[2], t20 = t[3], t11 = t[4], t02 = t[5];
         const u128 t30 = t[6], t21 = t[7], t12 = t[8], t03 = t[9];
         M[0] += t00;
@@ -1062,6 +1067,18 @@ __global__ __launch_bounds__(FX_BLOCK) void hu_tile_combine_kernel(HuArgs A, Ban
         M[9] += t03 + 3 * Y * t02 + 3 * Y * Y * t01 + Y * Y * Y * t00;
     }
     const u128 scale = gray ? 1 : (u128)A.on_value;
+    if (A.partial) {
+        const u64 limb = (1ull << 48) - 1;
+#pragma unroll
+        for (int k = 0; k < 10; k++) {
+            const u128 v = M[k] * scale;
+            int64_t *o = A.partial + (b * 10 + k) * 3;
+            o[0] = (int64_t)((u64)v & limb);
+            o[1] = (int64_t)((u64)(v >> 48) & limb);
+            o[2] = (int64_t)(u64)(v >> 96);
+        }
+        return;
+    }
     double raw[10];
 #pragma unroll
     for (int k = 0; k < 10; k++) {
@@ -1070,6 +1087,27 @@ __global__ __launch_bounds__(FX_BLOCK) void hu_tile_combine_kernel(HuArgs A, Ban
     }
     finalize_moments(raw, A.moments24 ? A.moments24 + b * 24 : nullptr, A.hu7 ? A.hu7 + b * 7 : nullptr,
                      A.hulog7 ? A.hulog7 + b * 7 : nullptr);
+}
+
+// Raw moments given as sums of 48-bit limbs (possibly added up over several
+// bands / ranks, so a limb may exceed 48 bits): one rounding to float64, then
+// the usual finalisation.
+__global__ __launch_bounds__(FX_BLOCK) void hu_from_partial_kernel(const int64_t *partial, int64_t B, double *moments24,
+                                                                 double *hu7, float *hulog7)
+{
+    typedef unsigned __int128 u128;
+    const int64_t b = (int64_t)blockIdx.x * FX_BLOCK + threadIdx.x;
+    if (b >= B)
+        return;
+    double raw[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+        const int64_t *l = partial + (b * 10 + k) * 3;
+        const u128 v = (u128)(u64)l[0] + ((u128)(u64)l[1] << 48) + ((u128)(u64)l[2] << 96);
+        raw[k] = fx_u128_to_double((u64)(v >> 64), (u64)v);
+    }
+    finalize_moments(raw, moments24 ? moments24 + b * 24 : nullptr, hu7 ? hu7 + b * 7 : nullptr,
+                     hulog7 ? hulog7 + b * 7 : nullptr);
 }
 
 // One wave per image: largest |projection on PC1| over the contour pixels and
@@ -1381,6 +1419,8 @@ extern "C" int fx_hu_batch_u8(const uint8_t *d_img, int64_t B, int H, int W, int
     A.redo_count = nullptr;
     A.redo_list = nullptr;
     A.only_redo = 0;
+    A.partial = nullptr;
+    A.y_offset = 0;
     A.tiles_x = A.tiles_y = 0;
     const bool aligned = ((uintptr_t)d_img % 16 == 0) && (pitch_bytes % 16 == 0) && (img_stride_bytes % 16 == 0 || B == 1);
     const size_t mask_lds = LDS_HEAD_BYTES + mask_bytes;
@@ -1510,6 +1550,79 @@ extern "C" int fx_hu_groupstat(const float *d_hulog7, const int64_t *d_group_off
     FX_REQUIRE((n + 255) / 256 <= 0x7fffffffLL, "fx_hu_groupstat: G too large");
     hipLaunchKernelGGL(hu_groupstat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        d_hulog7, d_group_offsets, G, d_out14);
+    FX_HIP_CHECK(hipGetLastError());
+    return FX_OK;
+}
+
+extern "C" int fx_hu_partial_u8(const uint8_t *d_img, int64_t B, int H, int W, int64_t pitch_bytes,
+                                int64_t img_stride_bytes, int thresh, int on_value, int64_t y_offset,
+                                int64_t *d_partial, void *stream)
+{
+    FX_REQUIRE(B >= 0, "fx_hu_partial_u8: B = %lld", (long long)B);
+    if (B == 0)
+        return FX_OK;
+    FX_REQUIRE(d_img && d_partial, "fx_hu_partial_u8: null pointer");
+    FX_REQUIRE(H >= 1 && W >= 1 && H <= 16384 && W <= 16384, "fx_hu_partial_u8: band %d x %d outside 1..16384", H, W);
+    FX_REQUIRE(y_offset >= 0 && y_offset <= (1ll << 20), "fx_hu_partial_u8: y_offset %lld outside 0..2^20",
+               (long long)y_offset);
+    FX_REQUIRE(pitch_bytes >= W, "fx_hu_partial_u8: pitch %lld < width %d", (long long)pitch_bytes, W);
+    FX_REQUIRE(B == 1 || img_stride_bytes >= pitch_bytes * (int64_t)(H - 1) + W,
+               "fx_hu_partial_u8: image stride %lld overlaps images", (long long)img_stride_bytes);
+    FX_REQUIRE(thresh < 255, "fx_hu_partial_u8: thresh %d must be < 255 (or negative)", thresh);
+    FX_REQUIRE(thresh < 0 || (on_value >= 1 && on_value <= 255), "fx_hu_partial_u8: on_value %d outside 1..255", on_value);
+    hipStream_t s = (hipStream_t)stream;
+    HuArgs A = {};
+    A.img = d_img;
+    A.B = B;
+    A.H = H;
+    A.W = W;
+    A.pitch = pitch_bytes;
+    A.stride = img_stride_bytes;
+    A.thresh = thresh;
+    A.on_value = on_value;
+    A.partial = d_partial;
+    A.y_offset = y_offset;
+    const bool aligned = ((uintptr_t)d_img % 16 == 0) && (pitch_bytes % 16 == 0) && (img_stride_bytes % 16 == 0 || B == 1);
+    const int mode = thresh < 0 ? MODE_GRAY : (thresh == 127 ? MODE_BIT7 : MODE_THRESH);
+    // always tiled: the combine step is where the offset is applied, in 128-bit integers
+    A.tiles_x = (W + TILE_W - 1) / TILE_W;
+    A.tiles_y = (H + TILE_H - 1) / TILE_H;
+    const int64_t blocks = B * A.tiles_x * A.tiles_y;
+    FX_REQUIRE(blocks <= 0x7fffffffLL, "fx_hu_partial_u8: too many tiles for one launch");
+    A.cpr = FX_WAVE;
+    A.bpw = 1;
+    A.nbands = FX_WAVES_PER_BLOCK;
+    A.hb = TILE_H / FX_WAVES_PER_BLOCK;
+    A.qcap = 0;
+    A.wave_lds = BAND_SLAB_BYTES;
+    BandScratch G = {};
+    G.sums = (u64 *)fx_scratch((size_t)blocks * BAND_SUMS * sizeof(u64), 1);
+    if (!G.sums)
+        return FX_ENOMEM;
+    int rc;
+    {
+        FxProfileScope prof(s);
+        rc = launch_band(A, G, mode, false, aligned && (W % 16 == 0),
+                         (size_t)BAND_LDS_WAVE + (size_t)FX_WAVES_PER_BLOCK * A.wave_lds + BAND_TAB_BYTES, s);
+    }
+    if (rc != FX_OK)
+        return rc;
+    hipLaunchKernelGGL(hu_tile_combine_kernel, dim3((unsigned)((B + FX_BLOCK - 1) / FX_BLOCK)), dim3(FX_BLOCK), 0, s, A, G,
+                       mode == MODE_GRAY ? 1 : 0);
+    FX_HIP_CHECK(hipGetLastError());
+    return FX_OK;
+}
+
+extern "C" int fx_hu_from_partial(const int64_t *d_partial, int64_t B, double *d_moments24, double *d_hu7,
+                                  float *d_hulog7, void *stream)
+{
+    FX_REQUIRE(B >= 0, "fx_hu_from_partial: B = %lld", (long long)B);
+    if (B == 0)
+        return FX_OK;
+    FX_REQUIRE(d_partial != nullptr, "fx_hu_from_partial: d_partial is NULL");
+    FX_REQUIRE(d_moments24 || d_hu7 || d_hulog7, "fx_hu_from_partial: no output requested");
+    hipLaunchKernelGGL(hu_from_partial_kernel, dim3((unsigned)((B + FX_BLOCK - 1) / FX_BLOCK)), dim3(FX_BLOCK), 0,
+                       (hipStream_t)stream, d_partial, B, d_moments24, d_hu7, d_hulog7);
     FX_HIP_CHECK(hipGetLastError());
     return FX_OK;
 }

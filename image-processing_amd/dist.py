@@ -58,3 +58,57 @@ def all_gather_rows(local: torch.Tensor, n_units: int) -> torch.Tensor:
     table = torch.empty((world * per, F), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(table, slot)
     return table[:n_units]
+
+
+# --------------------------------------------------------------------------
+# One image spread over the ranks as row bands (images too tall for one GPU's
+# share of a batch): the second, and last, exchange step of the path.
+# --------------------------------------------------------------------------
+LIMB_BITS = 48
+
+
+def band_range(height: int, rank: int, world: int, align: int = 256) -> Tuple[int, int]:
+    """Rows [y0, y1) of rank's band: equal shares rounded up to `align` rows
+    (the tile height of the moment kernel), later ranks may get fewer or none."""
+    per = -(-height // world) if world > 0 else height
+    per = -(-per // align) * align
+    y0 = min(height, rank * per)
+    return y0, min(height, y0 + per)
+
+
+def to_limbs(value: int) -> List[int]:
+    """A non-negative Python integer as three 48-bit limbs (what fx_hu_partial_u8 writes)."""
+    mask = (1 << LIMB_BITS) - 1
+    return [value & mask, (value >> LIMB_BITS) & mask, value >> (2 * LIMB_BITS)]
+
+
+def from_limbs(limbs) -> int:
+    """The integer a (possibly summed, unnormalised) limb triple stands for."""
+    return int(limbs[0]) + (int(limbs[1]) << LIMB_BITS) + (int(limbs[2]) << (2 * LIMB_BITS))
+
+
+def all_reduce_partial(partial: torch.Tensor) -> torch.Tensor:
+    """Sums the int64 [B, 10, 3] limb arrays of all ranks in place (one
+    all-reduce; exact, a limb grows by at most log2(world) bits).  Without an
+    initialised process group returns `partial` unchanged."""
+    if partial.dtype != torch.int64 or partial.dim() != 3 or tuple(partial.shape[1:]) != (10, 3):
+        raise ValueError("partial must be int64 [B, 10, 3]")
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.get_world_size() > (1 << 15):
+            raise ValueError("limb sums are exact for up to 2^15 ranks")
+        dist.all_reduce(partial, op=dist.ReduceOp.SUM)
+    return partial
+
+
+def hu_rowbands(band: torch.Tensor, y_offset: int, thresh: int = -1, on_value: int = 255, **outputs) -> dict:
+    """Hu features of images held as row bands across the ranks: every rank
+    passes its band [B, rows, W] (device tensor, possibly zero rows) and the
+    row it starts at; all ranks get the features of the whole images.  Exact:
+    integer partial moments, an integer all-reduce, one rounding."""
+    from . import engine
+    B = band.shape[0]
+    if band.shape[1] > 0:
+        partial = engine.hu_partial(band, y_offset, thresh, on_value)
+    else:
+        partial = torch.zeros((B, 10, 3), dtype=torch.int64, device=band.device)
+    return engine.hu_from_partial(all_reduce_partial(partial), **outputs)

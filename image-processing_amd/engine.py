@@ -76,6 +76,47 @@ def hu_batch(images: torch.Tensor, thresh: int = -1, on_value: int = 255, *, mom
     return out
 
 
+def hu_partial(bands: torch.Tensor, y_offset: int, thresh: int = -1, on_value: int = 255) -> torch.Tensor:
+    """Exact raw moments of row bands [B, H, W] that start at row y_offset of
+    taller images, in the tall image's coordinates: int64 [B, 10, 3] (three
+    48-bit limbs per moment).  Bands of one image are combined by adding these."""
+    _require_cuda(bands, "bands")
+    if bands.dtype != torch.uint8 or bands.dim() != 3:
+        raise ValueError(f"bands must be uint8 [B, H, W], got {bands.dtype} {tuple(bands.shape)}")
+    if bands.stride(2) != 1 and bands.shape[2] > 1:
+        raise ValueError("bands must have a unit stride along the row")
+    stream = _enter(bands.device)
+    B, H, W = bands.shape
+    out = torch.empty((B, 10, 3), dtype=torch.int64, device=bands.device)
+    if B == 0:
+        return out
+    pitch = bands.stride(1) if H > 1 else W
+    stride = bands.stride(0) if B > 1 else pitch * H
+    _lib.call("fx_hu_partial_u8", bands.data_ptr(), B, H, W, pitch, stride, int(thresh), int(on_value), int(y_offset),
+              out.data_ptr(), stream)
+    return out
+
+
+def hu_from_partial(partial: torch.Tensor, *, moments: bool = False, hu: bool = False) -> dict:
+    """Finalises summed limb arrays [B, 10, 3] (see hu_partial): {"hulog7"} and on request "moments24", "hu7"."""
+    _require_cuda(partial, "partial")
+    if partial.dtype != torch.int64 or partial.dim() != 3 or tuple(partial.shape[1:]) != (10, 3) \
+            or not partial.is_contiguous():
+        raise ValueError("partial must be contiguous int64 [B, 10, 3]")
+    stream = _enter(partial.device)
+    B = partial.shape[0]
+    dev = partial.device
+    out = {"hulog7": torch.empty((B, HU_COLS), dtype=torch.float32, device=dev)}
+    if moments:
+        out["moments24"] = torch.empty((B, MOMENT_COLS), dtype=torch.float64, device=dev)
+    if hu:
+        out["hu7"] = torch.empty((B, HU_COLS), dtype=torch.float64, device=dev)
+    if B:
+        _lib.call("fx_hu_from_partial", partial.data_ptr(), B, _ptr(out.get("moments24")), _ptr(out.get("hu7")),
+                  out["hulog7"].data_ptr(), stream)
+    return out
+
+
 def silhouette_batch(images: torch.Tensor, resolution: int = 224, crop_margin: float = 0.05,
                      preprocess_crop: bool = True, min_size: int = -1, *, info: bool = False) -> dict:
     """Cleaned 0/255 silhouettes [B, resolution, resolution] of a batch of gray

@@ -124,6 +124,26 @@ int fx_pca_batch_f32(const float *d_pts, const int64_t *d_offsets, int64_t B,
                      float *d_out, double *d_eig, void *stream);
 
 /*
+ * Row-band form of fx_hu_batch_u8 for images that are split over several GPUs
+ * (no reference counterpart: the reference handles one image per process; the
+ * arithmetic is that of cv2.moments, src/features/extract_2d_hu.py:449).  Each
+ * of the B images is a band of H rows that starts at row y_offset of a taller
+ * image.  fx_hu_partial_u8 writes the band's exact integer raw moments m00,
+ * m10, m01, m20, m11, m02, m30, m21, m12, m03 in the tall image's coordinates
+ * as three 48-bit limbs each (value = l0 + l1 * 2^48 + l2 * 2^96), d_partial
+ * int64 [B, 10, 3].  Limb arrays of the bands of one image are simply added
+ * (an integer all-reduce over the ranks; up to 2^15 summands cannot overflow);
+ * fx_hu_from_partial rounds the sums once to float64 and finalises them
+ * exactly as fx_hu_batch_u8 does, so the result equals the unsplit image's.
+ */
+int fx_hu_partial_u8(const uint8_t *d_img, int64_t B, int H, int W,
+                     int64_t pitch_bytes, int64_t img_stride_bytes, int thresh,
+                     int on_value, int64_t y_offset, int64_t *d_partial,
+                     void *stream);
+int fx_hu_from_partial(const int64_t *d_partial, int64_t B, double *d_moments24,
+                       double *d_hu7, float *d_hulog7, void *stream);
+
+/*
  * Silhouette preprocessing of B gray views H x W (both <= 512), the step the
  * reference runs in front of the Hu moments, on the branch it takes when
  * OpenCV is not installed.  Replaces, per view,

@@ -1,6 +1,7 @@
 """Parity of the HIP Hu path (through the C ABI) with the CPU oracle."""
 import numpy as np
 import pytest
+import torch
 
 from conftest import pkg
 
@@ -201,3 +202,29 @@ def test_full_size_properties(gpu):
     hb = eng.hu_batch(canvas_b, hu=True)["hu7"]
     scale = ha.abs().max(dim=0).values
     assert torch.all((ha - hb).abs() <= 1e-6 * ha.abs() + 1e-7 * scale)
+
+
+def test_row_bands_equal_whole_image(gpu, oracle):
+    """An image cut into row bands: the summed limb arrays finalise to exactly
+    the unsplit image's moments (the multi-GPU path for very tall images)."""
+    eng, fxd = pkg("engine"), pkg("dist")
+    rng = np.random.default_rng(12)
+    for (H, W, thresh, on_value, world) in ((4096, 3000, 127, 255, 3), (8192, 8192, -1, 255, 8), (700, 333, 90, 7, 4),
+                                            (300, 64, 127, 255, 2)):
+        img = torch.from_numpy(rng.integers(0, 256, (2, H, W), dtype=np.uint8)).to(gpu)
+        whole = eng.hu_batch(img, thresh=thresh, on_value=on_value, moments=True, hu=True)
+        total = torch.zeros((2, 10, 3), dtype=torch.int64, device=gpu)
+        for r in range(world):
+            y0, y1 = fxd.band_range(H, r, world)
+            if y1 > y0:
+                total += eng.hu_partial(img[:, y0:y1], y0, thresh, on_value)
+        got = eng.hu_from_partial(total, moments=True, hu=True)
+        for k in ("moments24", "hu7", "hulog7"):
+            assert torch.equal(got[k], whole[k]), f"{k} differs for {H}x{W} in {world} bands"
+        # the limbs stand for the exact integers
+        if H <= 700:
+            raw = oracle.raw_moments_exact(oracle.binarise(img[0].cpu().numpy(), thresh, on_value))
+            host = total[0].cpu().numpy()
+            assert [fxd.from_limbs(host[k]) for k in range(10)] == [int(v) for v in raw]
+    out = fxd.hu_rowbands(img, 0, thresh, on_value, moments=True)       # single process: no group, one band
+    assert torch.equal(out["moments24"], whole["moments24"])

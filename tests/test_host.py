@@ -160,6 +160,20 @@ for n_units in (10, 7, 1, 2):
     table = fx.all_gather_rows(local, n_units)
     want = torch.arange(n_units, dtype=torch.float32).unsqueeze(1).repeat(1, 24) + torch.arange(24) / 100.0
     assert table.shape == (n_units, 24) and torch.equal(table, want), (rank, n_units)
+# one tall image as row bands: exact partial moments in the image's coordinates
+# (here from the oracle's integer arithmetic), one integer all-reduce of limbs
+import numpy as np
+from oracle import cpu_ref
+img = np.random.default_rng(3).integers(0, 256, (600, 90), dtype=np.uint8)
+y0, y1 = fx.band_range(600, rank, world)
+band = img[y0:y1].astype(object)
+x = np.arange(90, dtype=object); y = np.arange(y0, y1, dtype=object)[:, None]
+pq = [(0, 0), (1, 0), (0, 1), (2, 0), (1, 1), (0, 2), (3, 0), (2, 1), (1, 2), (0, 3)]
+mine = [int((band * x ** p * y ** q).sum()) for p, q in pq]
+part = torch.tensor([[fx.to_limbs(v) for v in mine]], dtype=torch.int64)
+total = fx.all_reduce_partial(part)
+got = [fx.from_limbs(total[0, k].tolist()) for k in range(10)]
+assert got == cpu_ref.raw_moments_exact(img), (rank, got[:3])
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
@@ -334,3 +348,20 @@ def test_native_png_decode_equals_pil(tmp_path):
     assert status.tolist() == [4, 4, 6, 3, 3, 3, 1]
     assert found[2].tolist() == [50, W]
     assert ing.image_size(paths[0]) == (H, W) and ing.image_size(tmp_path / "none.png") is None
+
+
+def test_band_ranges_and_limbs():
+    fxd = pkg("dist")
+    for height, world in ((8192, 8), (8192, 3), (700, 4), (300, 2), (1, 8), (5000, 1)):
+        rows = [fxd.band_range(height, r, world) for r in range(world)]
+        assert rows[0][0] == 0 and rows[-1][1] == height
+        assert all(a[1] == b[0] for a, b in zip(rows, rows[1:]))               # no gap, no overlap
+        assert all(y0 % 256 == 0 for y0, y1 in rows if y1 > y0)                 # bands start on a tile boundary
+    for v in (0, 1, (1 << 48) - 1, 1 << 48, 12345678901234567890123456789, (1 << 127) + 5):
+        assert fxd.from_limbs(fxd.to_limbs(v)) == v and all(0 <= x for x in fxd.to_limbs(v))
+    # sums of limb triples stand for the sum of the integers, before any carry is propagated
+    vals = [987654321987654321987654321 * (k + 1) for k in range(200)]
+    acc = [0, 0, 0]
+    for v in vals:
+        acc = [a + b for a, b in zip(acc, fxd.to_limbs(v))]
+    assert fxd.from_limbs(acc) == sum(vals) and max(acc) < 1 << 63
