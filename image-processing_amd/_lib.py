@@ -38,6 +38,7 @@ SIGNATURES = {
                                      c_void_p]),
     "fx_center_scale": (c_int, [c_void_p, c_int, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fx_fps_f32": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fx_allgather_features": (c_int, [c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p]),
     "fx_read_npy_points_f32": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_int]),
     "fx_write_npy_rows_f32": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int]),
     "fx_decode_png_gray_u8": (c_int, [c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int]),

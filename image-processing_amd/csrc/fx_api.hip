@@ -153,3 +153,62 @@ double fx_profile_last_ms(void)
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------- collective
+// The one exchange step of the sharded path for callers that hold an RCCL
+// communicator of their own.  RCCL is looked up at the first call (the copy
+// already loaded into the process, e.g. by PyTorch, if there is one), so the
+// library itself has no link-time dependency on it.
+#include <dlfcn.h>
+
+namespace {
+
+typedef int (*fx_nccl_allgather_t)(const void *, void *, size_t, int, void *, hipStream_t);
+typedef const char *(*fx_nccl_errstr_t)(int);
+fx_nccl_allgather_t g_nccl_allgather = nullptr;
+fx_nccl_errstr_t g_nccl_errstr = nullptr;
+constexpr int kNcclFloat32 = 7;  // ncclFloat32 in rccl.h
+
+bool load_rccl()
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_nccl_allgather)
+        return true;
+    void *h = nullptr;
+    const char *names[] = {"librccl.so.1", "librccl.so"};
+    for (const char *n : names)
+        if (!h)
+            h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+    for (const char *n : names)
+        if (!h)
+            h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (!h)
+        return false;
+    g_nccl_allgather = (fx_nccl_allgather_t)dlsym(h, "ncclAllGather");
+    g_nccl_errstr = (fx_nccl_errstr_t)dlsym(h, "ncclGetErrorString");
+    return g_nccl_allgather != nullptr;
+}
+
+}  // namespace
+
+extern "C" int fx_allgather_features(const void *d_local, int64_t local_rows, int row_floats, void *d_global,
+                                     void *rccl_comm, void *stream)
+{
+    FX_REQUIRE(local_rows >= 0 && row_floats >= 1, "fx_allgather_features: %lld rows of %d floats",
+               (long long)local_rows, row_floats);
+    FX_REQUIRE(rccl_comm != nullptr, "fx_allgather_features: rccl_comm is NULL");
+    if (local_rows == 0)
+        return FX_OK;
+    FX_REQUIRE(d_local && d_global, "fx_allgather_features: null buffer");
+    if (!load_rccl()) {
+        fx_set_error("fx_allgather_features: librccl.so.1 could not be loaded (%s)", dlerror());
+        return FX_ENODEV;
+    }
+    const int rc = g_nccl_allgather(d_local, d_global, (size_t)local_rows * (size_t)row_floats, kNcclFloat32, rccl_comm,
+                                    (hipStream_t)stream);
+    if (rc != 0) {
+        fx_set_error("fx_allgather_features: ncclAllGather failed: %s", g_nccl_errstr ? g_nccl_errstr(rc) : "?");
+        return FX_EHIP;
+    }
+    return FX_OK;
+}

@@ -216,6 +216,18 @@ int fx_fps_f32(const float *d_pts, const int64_t *h_offsets, int64_t B,
                float *d_sampled, void *stream);
 
 /*
+ * The exchange step of the sharded path, for callers that hold an RCCL
+ * communicator (ncclComm_t) of their own instead of torch.distributed: an
+ * all-gather of every rank's [local_rows, row_floats] float32 feature block
+ * into d_global [world * local_rows, row_floats], rank-major, enqueued on
+ * `stream`.  Every rank passes the same local_rows (pad the last shard).  The
+ * reference has no counterpart: its pool workers return rows to the parent
+ * process (extract_2d_hu.py:746-760).  RCCL is resolved at the first call.
+ */
+int fx_allgather_features(const void *d_local, int64_t local_rows, int row_floats,
+                          void *d_global, void *rccl_comm, void *stream);
+
+/*
  * Host file I/O on native threads (no device work).  Per-file status codes:
  */
 #define FX_IO_OK 0

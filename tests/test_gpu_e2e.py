@@ -138,3 +138,41 @@ def test_hu_directory_run_mixed_files(gpu, tmp_path, oracle, c_oracle, hu_panels
             got = df.loc[sid, hu.HU_COLS[1:15]].to_numpy(dtype=np.float64).astype(np.float32)
             np.testing.assert_allclose(got[:7], want[:7], rtol=2e-6)
             np.testing.assert_allclose(got[7:], want[7:], rtol=1e-4, atol=1e-6)
+
+
+def test_allgather_features_on_a_one_rank_communicator(gpu):
+    """fx_allgather_features with an RCCL communicator made by the caller (one
+    rank here; the N-rank case is the same call)."""
+    import ctypes
+    import torch
+    lib = pkg("_lib")
+    pkg("engine").synth_points(1, 8, device=gpu)            # library initialised on the device
+    rccl = None
+    with open("/proc/self/maps") as fh:                      # the copy PyTorch has already loaded
+        for line in fh:
+            if "librccl" in line:
+                rccl = ctypes.CDLL(line.split()[-1])
+                break
+    if rccl is None:
+        rccl = ctypes.CDLL("librccl.so.1")
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    try:
+        local = torch.arange(5 * 24, dtype=torch.float32, device=gpu).reshape(5, 24) / 7
+        table = torch.full((5, 24), -1.0, dtype=torch.float32, device=gpu)
+        stream = torch.cuda.current_stream().cuda_stream
+        lib.call("fx_allgather_features", local.data_ptr(), 5, 24, table.data_ptr(), comm, stream)
+        torch.cuda.synchronize()
+        assert torch.equal(table, local)
+        with pytest.raises(lib.FxError, match="rccl_comm is NULL"):
+            lib.call("fx_allgather_features", local.data_ptr(), 5, 24, table.data_ptr(), None, stream)
+    finally:
+        rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        rccl.ncclCommDestroy(comm)
