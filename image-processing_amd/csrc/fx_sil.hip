@@ -956,12 +956,9 @@ extern "C" int fx_silhouette_batch_u8(const uint8_t *d_img, int64_t B, int H, in
     A.tr = tr;
     const size_t blur_lds = (size_t)(tr + 2 * SIL_HALO) * Wp + 256 * sizeof(uint32_t);
     const size_t mask_lds = (size_t)3 * rows * wpr * sizeof(uint32_t);
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (mask_lds > 48 * 1024)  // beyond the default limit of dynamic LDS; set per call: the current device may differ
         FX_HIP_CHECK(hipFuncSetAttribute((const void *)sil_mask_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         3 * SIL_MAX_SIDE * (SIL_MAX_SIDE / 32) * (int)sizeof(uint32_t)));
-        attr_set = true;
-    }
+                                         (int)mask_lds));
 
     for (int64_t b0 = 0; b0 < B; b0 += chunk) {
         const int64_t nb = B - b0 < chunk ? B - b0 : chunk;
