@@ -411,13 +411,12 @@ def main(argv=None) -> int:
               "overwrite": bool(args.overwrite), "reports_dir": str(reports_dir)}
     tasks = [(sid, str(d), config) for sid, d in ids]
     results: List[Dict[str, Any]] = []
-    if args.workers:
-        import os
-        os.environ["FX_DECODE_WORKERS"] = str(int(args.workers))
     step = max(1, int(args.batch_samples))
     from . import ingest
+    workers = int(args.workers) if args.workers else None
     # the next batch is decoded while the current one is on the device
-    for decoded in ingest.prefetch(decode_samples, (tasks[i:i + step] for i in range(0, len(tasks), step))):
+    for decoded in ingest.prefetch(lambda chunk: decode_samples(chunk, workers),
+                                   (tasks[i:i + step] for i in range(0, len(tasks), step))):
         results.extend(finish_samples(decoded))
     out_csv = out_dir / "hu_features_table.csv"
     append_to_csv(results_to_records(results), out_csv, overwrite=args.overwrite)

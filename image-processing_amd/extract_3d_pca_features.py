@@ -330,13 +330,12 @@ def main(argv=None) -> int:
     tasks = [(str(p), str(sampled_dir), str(out_dir), int(args.n_bins), bool(args.normalize), bool(args.overwrite),
               manifest_map, str(reports_dir)) for p in files]
     from . import ingest
-    if args.workers:
-        import os
-        os.environ["FX_DECODE_WORKERS"] = str(int(args.workers))
+    workers = int(args.workers) if args.workers else None
     step = max(1, int(args.batch_files))
     results: List[dict] = []
     # the next batch is read while the current one is on the device
-    for batch in ingest.prefetch(load_files, (tasks[i:i + step] for i in range(0, len(tasks), step))):
+    for batch in ingest.prefetch(lambda chunk: load_files(chunk, workers),
+                                 (tasks[i:i + step] for i in range(0, len(tasks), step))):
         results.extend(finish_files(batch))
     records = [r["record"] for r in results if r.get("success")]
     if not records:
