@@ -112,3 +112,40 @@ def hu_rowbands(band: torch.Tensor, y_offset: int, thresh: int = -1, on_value: i
     else:
         partial = torch.zeros((B, 10, 3), dtype=torch.int64, device=band.device)
     return engine.hu_from_partial(all_reduce_partial(partial), **outputs)
+
+
+class GatherPipeline:
+    """All-gathers of equal-sized per-rank blocks that overlap with the next
+    step's kernels: submit() enqueues the collective asynchronously and returns
+    at once; at most `depth` collectives are in flight (the oldest is waited for
+    before another one is issued), drain() waits for the rest and returns the
+    last table.  Without a process group every call is a no-op that hands the
+    block back."""
+
+    def __init__(self, depth: int = 2):
+        self.depth = max(1, int(depth))
+        self.pending: List[tuple] = []
+        self.last = None
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def submit(self, block: torch.Tensor) -> None:
+        if not self.active:
+            self.last = block
+            return
+        while len(self.pending) >= self.depth:
+            self._pop()
+        block = block.contiguous()
+        table = torch.empty((dist.get_world_size() * block.shape[0],) + tuple(block.shape[1:]), dtype=block.dtype,
+                            device=block.device)
+        work = dist.all_gather_into_tensor(table, block, async_op=True)
+        self.pending.append((work, table, block))   # the block must stay alive until the collective has read it
+
+    def _pop(self) -> None:
+        work, table, _block = self.pending.pop(0)
+        work.wait()
+        self.last = table
+
+    def drain(self):
+        while self.pending:
+            self._pop()
+        return self.last

@@ -160,6 +160,18 @@ for n_units in (10, 7, 1, 2):
     table = fx.all_gather_rows(local, n_units)
     want = torch.arange(n_units, dtype=torch.float32).unsqueeze(1).repeat(1, 24) + torch.arange(24) / 100.0
     assert table.shape == (n_units, 24) and torch.equal(table, want), (rank, n_units)
+# pipelined all-gathers: several in flight, tables complete and in submission order
+pipe = fx.GatherPipeline(depth=2)
+seen = []
+for step in range(5):
+    pipe.submit(torch.full((3, 4), float(10 * step + rank)))
+    if pipe.last is not None:
+        seen.append(float(pipe.last[0, 0]))
+    assert len(pipe.pending) <= 2
+last = pipe.drain()
+want = torch.cat([torch.full((3, 4), float(40 + r)) for r in range(world)])
+assert torch.equal(last, want) and not pipe.pending, (rank, last)
+assert seen == sorted(seen) and all(v % 10 == 0 for v in seen), seen
 # one tall image as row bands: exact partial moments in the image's coordinates
 # (here from the oracle's integer arithmetic), one integer all-reduce of limbs
 import numpy as np
