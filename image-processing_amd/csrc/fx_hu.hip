@@ -623,28 +623,33 @@ __global__ __launch_bounds__(FX_BLOCK) void hu_image_kernel(HuArgs A)
 // neighbouring lanes, so contour pixels are found while the image streams in.
 // Only contour segments (16-pixel masks with at least one contour pixel, about
 // 0.5 % of the chunks of a shape image) leave the registers: they go to an LDS
-// queue, the block sums them evenly, and the queue is copied to global scratch.
+// queue that never leaves the block.  Once the image has streamed through, the
+// block sums its moments, and for the contour descriptor every wave walks its
+// own part of the queue twice (largest |projection| on the first principal
+// axis, then the histogram): nothing but 16 sums, 4 counters and the
+// histogram is written to memory.
 //
-// The streaming kernel does no floating point at all.  Two small kernels
-// follow: hu_finalize_kernel (one lane per image: central / normalised
-// moments, Hu, log, contour covariance and eigen-solve -- serial float64 code
-// that would idle 255 of 256 threads inside the streaming kernel) and
-// hu_contour_hist_kernel (one wave per image: |projection| maximum and
-// histogram over the queued segments).
-constexpr int BAND_LDS_COUNTERS = LDS_HEAD_BYTES;          // 16 B: queue length
-constexpr int BAND_LDS_EDGES = BAND_LDS_COUNTERS + 16;     // top/bottom row masks of every band
-// per-wave region: first the wave's part of the segment queue, later (the queue
-// has been consumed by then) the 4 KiB slab of the wave-level reduction
+// hu_finalize_kernel follows (one lane per image: central / normalised
+// moments, Hu, log, the descriptor's nine leading scalars -- serial float64
+// code that would idle 255 of 256 threads inside the streaming kernel).
+constexpr int BAND_LDS_COUNTERS = LDS_HEAD_BYTES;          // 16 B: segments queued by each wave
+constexpr int BAND_LDS_EDGES = BAND_LDS_COUNTERS + 16;     // top/bottom row masks of every band; later 4 x 64 histogram counters
+// per-wave region: the wave's part of the segment queue (contour variant) or
+// the 4 KiB slab of the wave-level reduction (moments only); the contour
+// variant has its slabs, later the lists of undecided segments, behind the
+// lookup table
 constexpr int BAND_LDS_WAVE = BAND_LDS_EDGES + 4 * FX_BLOCK;
 constexpr int BAND_SLAB_BYTES = 4096;
+#ifndef BAND_VPP_CONTOUR
+#define BAND_VPP_CONTOUR 4
+#endif
+constexpr int BAND_CSLAB_BYTES = BAND_VPP_CONTOUR * FX_WAVE * 8;  // slab of the contour variant
 constexpr int TILE_W = 1024, TILE_H = 256;                 // tiled mode: one block per tile, 64 rows per wave
 constexpr int BAND_SUMS = 16;                              // u64 per image: 10 raw moments + 6 contour sums
 
 struct BandScratch {
     u64 *sums;         // [B][16]
     uint32_t *qcount;  // [B][4] segments each wave found (above qcap / 4: the mask kernel redoes the image)
-    uint32_t *queue;   // [B][4][qcap / 4] segment = 16-pixel mask | (y << 6 | chunk) << 16
-    double *params;    // [B][4] contour centroid x, y and first principal axis x, y
     uint32_t *redo_count;  // [1] zeroed before the launches
     uint32_t *redo_list;   // [B] images for the mask kernel
 };
@@ -668,6 +673,178 @@ __device__ __forceinline__ void segment_sums(uint32_t bits, uint32_t &r0, uint32
     r2 += 4 * __popc(bits & 0xAAAAu & 0xCCCCu) + 8 * __popc(bits & 0xAAAAu & 0xF0F0u);
     r2 += 16 * __popc(bits & 0xAAAAu & 0xFF00u) + 16 * __popc(bits & 0xCCCCu & 0xF0F0u);
     r2 += 32 * __popc(bits & 0xCCCCu & 0xFF00u) + 64 * __popc(bits & 0xF0F0u & 0xFF00u);
+}
+
+// Tail of the streaming kernel, contour variant: |projection on PC1| maximum
+// and histogram of the image's contour pixels, each wave over the segments it
+// queued in LDS.  Along a segment the signed projection is monotone in x, so
+// its largest magnitude is at an end, and a segment whose two ends fall into
+// the same bin on the same side of zero belongs to that bin as a whole.
+// Float32 only sorts out the cases that are beyond doubt: everything within
+// `eps` of a decision boundary is decided in float64, so the results are those
+// of the float64 formula.  Every thread of the block calls this after the
+// barrier that completed `red`; the branch conditions below are block-uniform.
+__device__ __forceinline__ void band_contour_hist(const HuArgs &A, const int64_t b, unsigned char *lds_raw,
+                                                  uint32_t *wq, const int qn)
+{
+    const u64 *red = reinterpret_cast<const u64 *>(lds_raw);
+    double *bcast = reinterpret_cast<double *>(lds_raw + LDS_RED_BYTES);
+    const uint32_t *cnt = reinterpret_cast<const uint32_t *>(lds_raw + BAND_LDS_COUNTERS);
+    const int t = threadIdx.x, lane = fx_lane(), wave = fx_wave();
+    const uint32_t wcap = (uint32_t)(A.qcap >> 2);
+    if (cnt[0] > wcap || cnt[1] > wcap || cnt[2] > wcap || cnt[3] > wcap)
+        return;  // the mask kernel redoes the image
+    u64 cs[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+        cs[k] = red[10 + k] + red[BAND_SUMS + 10 + k] + red[2 * BAND_SUMS + 10 + k] + red[3 * BAND_SUMS + 10 + k];
+    const u64 n = cs[0];
+    if (n < 3)
+        return;  // hu_finalize_kernel writes the NaN row
+    // centroid and first principal axis exactly as hu_finalize_kernel derives
+    // them (every lane computes the same values: no broadcast, no barrier)
+    const double dn = (double)n;
+    const double inv = 1.0 / (dn * (double)(n - 1));
+    const i64 sx = (i64)cs[1], sy = (i64)cs[2];
+    const double cxx = (double)((i64)(n * cs[3]) - sx * sx) * inv;
+    const double cxy = (double)((i64)(n * cs[4]) - sx * sy) * inv;
+    const double cyy = (double)((i64)(n * cs[5]) - sy * sy) * inv;
+    double lam[3], v1[3];
+    fx_eig3(cxx, cxy, 0.0, cyy, 0.0, 0.0, lam, v1);
+    const double ccx = (double)sx / dn, ccy = (double)sy / dn, vx = v1[0], vy = v1[1];
+    const float cx32 = (float)ccx, cy32 = (float)ccy, vx32 = (float)vx, vy32 = (float)vy;
+
+    // the edge rows have been exchanged before the last barrier: their LDS holds the four histograms now
+    uint32_t *hist_all = reinterpret_cast<uint32_t *>(lds_raw + BAND_LDS_EDGES);
+    uint32_t *hist = hist_all + wave * FX_WAVE;
+    hist[lane] = 0;
+
+    auto sproj = [&](uint32_t X, int i, double dyv) -> double {
+        return fma(dyv, vy, ((double)(int)(X + i) - ccx) * vx);
+    };
+    auto larger = [&](uint32_t e, double best) -> double {
+        const uint32_t bits = e & 0xFFFFu, pos = e >> 16;
+        const uint32_t X = (pos & 63u) * 16u;
+        const double dy = (double)(int)(pos >> 6) - ccy;
+        const double slo = sproj(X, __ffs((int)bits) - 1, dy), shi = sproj(X, 31 - __clz((int)bits), dy);
+        return fmax(best, fmax(fabs(slo), fabs(shi)));
+    };
+    auto ends32 = [&](uint32_t e, float &slo, float &shi) {
+        const uint32_t bits = e & 0xFFFFu, pos = e >> 16;
+        const float xb = (float)(int)((pos & 63u) * 16u) - cx32;
+        const float ty = ((float)(int)(pos >> 6) - cy32) * vy32;
+        const float lo = (float)(__ffs((int)bits) - 1), hi = (float)(31 - __clz((int)bits));
+        slo = fmaf(xb + lo, vx32, ty);
+        shi = fmaf(xb + hi, vx32, ty);
+    };
+    // Segments whose bin float32 cannot settle are collected (ballot-compacted,
+    // so that the slower code runs with full lanes) at the front of the queue
+    // itself: the list never gets ahead of the reading position, and every lane
+    // has read its entry of a round before any lane writes.
+    uint32_t *list = wq;
+    uint32_t nl = 0;  // wave-uniform
+    auto defer = [&](bool want, uint32_t e) {
+        const unsigned long long m = __ballot(want);
+        if (m) {
+            const uint32_t at = nl + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (want)
+                list[at] = e;
+            nl += (uint32_t)__popcll(m);
+        }
+    };
+    auto list_ready = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    // ---- largest |projection| ---------------------------------------------------
+    float top32 = 0.0f;
+    for (int i = lane; i < qn; i += FX_WAVE) {
+        float a, c;
+        ends32(wq[i], a, c);
+        top32 = fmaxf(top32, fmaxf(fabsf(a), fabsf(c)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        top32 = fmaxf(top32, __shfl_xor(top32, o, FX_WAVE));
+    // float32 error bound of a projection (coordinates below 1024, |v| <= 1): a few 1e-4; the factor is generous
+    const float eps_w = 4e-7f * (top32 + fabsf(cx32) + fabsf(cy32) + 1024.0f);
+    // the wave's exact maximum is among the few segments within the error bound of the float32 one
+    double top = 0.0;
+    for (int i = lane; i < qn; i += FX_WAVE) {
+        const uint32_t e = wq[i];
+        float a, c;
+        ends32(e, a, c);
+        if (fmaxf(fabsf(a), fabsf(c)) >= top32 - 2.0f * eps_w)
+            top = larger(e, top);
+    }
+    top = fx_wave_max_f64(top);
+    if (lane == 0)
+        bcast[wave] = top;
+    __syncthreads();
+    top = fmax(fmax(bcast[0], bcast[1]), fmax(bcast[2], bcast[3]));
+
+    const int nb = A.n_bins;
+    float *out = A.cpca + b * (9 + nb) + 9;
+    if (!(top > 0.0)) {
+        if (t < nb)
+            out[t] = t == 0 ? 1.0f : 0.0f;
+        return;
+    }
+    // ---- histogram ----------------------------------------------------------------
+    const double step = top / (double)nb;
+    const double inv_step = (double)nb / top;
+    const float eps = 4e-7f * ((float)top * 1.000001f + fabsf(cx32) + fabsf(cy32) + 1024.0f);
+    // float32 bin of |s|, or -1 when |s| / step is within `margin` of an integer
+    const float inv32 = (float)inv_step;
+    const float margin = 2.0f * eps * inv32 + 1e-5f * (float)nb;
+    auto bin32 = [&](float v) -> int {
+        const float q = fabsf(v) * inv32;
+        const float f = floorf(q);
+        const float frac = q - f;
+        if (frac < margin || frac > 1.0f - margin || q >= (float)nb)
+            return -1;
+        return (int)f;
+    };
+    for (int base = 0; base < qn; base += FX_WAVE) {
+        const int i = base + lane;
+        const uint32_t e = i < qn ? wq[i] : 0u;
+        bool whole = false;
+        if (e) {
+            float a, c;
+            ends32(e, a, c);
+            const int ba = bin32(a), bc = bin32(c);
+            const bool same_side = (a > eps && c > eps) || (a < -eps && c < -eps);
+            whole = ba >= 0 && ba == bc && same_side;
+            if (whole)
+                atomicAdd(&hist[ba], (uint32_t)__popc(e & 0xFFFFu));
+        }
+        defer(e != 0u && !whole, e);
+    }
+    list_ready();
+    // one pixel at a time: float32 where it is certain, float64 otherwise
+    for (uint32_t i = lane; i < nl; i += FX_WAVE) {
+        const uint32_t e = list[i];
+        const uint32_t pos = e >> 16;
+        const uint32_t X = (pos & 63u) * 16u;
+        const float xb = (float)(int)X - cx32;
+        const float t32 = ((float)(int)(pos >> 6) - cy32) * vy32;
+        const double dy = (double)(int)(pos >> 6) - ccy;
+        uint32_t rest = e & 0xFFFFu;
+        while (rest) {
+            const int k = __ffs((int)rest) - 1;
+            rest &= rest - 1;
+            int bin = bin32(fmaf(xb + (float)k, vx32, t32));
+            if (bin < 0)
+                bin = fx_hist_bin(fabs(sproj(X, k, dy)), step, inv_step, nb);
+            atomicAdd(&hist[bin], 1u);
+        }
+    }
+    __syncthreads();
+    if (t < nb) {
+        const uint32_t h = hist_all[t] + hist_all[FX_WAVE + t] + hist_all[2 * FX_WAVE + t] + hist_all[3 * FX_WAVE + t];
+        out[t] = (float)((double)h / (double)n);
+    }
 }
 
 #ifndef FX_BAND_WAVES
@@ -748,7 +925,8 @@ __global__ __launch_bounds__(FX_BLOCK, FX_BAND_WAVES) void hu_band_kernel(HuArgs
 
     // ---- contour segments -----------------------------------------------------
     // Each wave appends to its own quarter of the LDS queue; the slot of a lane
-    // comes from a ballot, so no atomic is needed.
+    // comes from a ballot, so no atomic is needed.  A segment is the 16-pixel
+    // mask | (row << 6 | chunk) << 16.
     const int wcap = A.qcap >> 2;
     uint32_t *wq = reinterpret_cast<uint32_t *>(lds_raw + BAND_LDS_WAVE + wave * wave_bytes);
     uint32_t wn = 0;  // wave-uniform: segments this wave has queued (may run past wcap: overflow)
@@ -865,6 +1043,7 @@ __global__ __launch_bounds__(FX_BLOCK, FX_BAND_WAVES) void hu_band_kernel(HuArgs
 
     constexpr int NV = CONTOUR ? BAND_SUMS : 10;
     u64 V[NV];
+    int qn = 0;  // segments in this wave's part of the queue
     {
         const u64 X = (u64)x0, X2 = X * X, X3 = X2 * X;
         V[0] = T.t00;
@@ -906,15 +1085,13 @@ __global__ __launch_bounds__(FX_BLOCK, FX_BAND_WAVES) void hu_band_kernel(HuArgs
         // one wave complete in order, so no block barrier is needed here.
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const int qn = wn > (uint32_t)wcap ? 0 : (int)wn;  // overflow: the mask kernel redoes the image
+        qn = wn > (uint32_t)wcap ? 0 : (int)wn;  // overflow: the mask kernel redoes the image
 
         // sums over contour pixels: n, sum x, sum y, sum x^2, sum xy, sum y^2;
         // at most 16 segments per lane, so 32-bit partial sums cannot overflow
         uint32_t s0 = 0, sx = 0, sy = 0, sxx = 0, sxy = 0, syy = 0;
-        uint32_t *gq = G.queue + (b * FX_WAVES_PER_BLOCK + wave) * wcap;
         for (int i = lane; i < qn; i += FX_WAVE) {
             const uint32_t e = wq[i];
-            gq[i] = e;
             const uint32_t pos = e >> 16;
             const uint32_t y = pos >> 6, X = (pos & 63u) * 16u;
             uint32_t r0, r1, r2;
@@ -933,39 +1110,49 @@ __global__ __launch_bounds__(FX_BLOCK, FX_BAND_WAVES) void hu_band_kernel(HuArgs
         V[NV - 3] = sxx;
         V[NV - 2] = sxy;
         V[NV - 1] = syy;
-        if (lane == 0)
+        if (lane == 0) {
             G.qcount[b * FX_WAVES_PER_BLOCK + wave] = wn;
+            reinterpret_cast<uint32_t *>(lds_raw + BAND_LDS_COUNTERS)[wave] = wn;
+        }
     }
     // ---- block sums ---------------------------------------------------------------
-    // Wave level: the lanes park eight values at a time in the wave's 4 KiB LDS
-    // slab as [value][lane]; lane l then adds the eight lanes 8*(l&7).. of value
-    // l>>3 and three butterfly steps finish the 64-lane sum.  (16 LDS accesses
+    // Wave level: the lanes park VPP values at a time in the wave's LDS slab as
+    // [value][lane]; lane l then adds VPP adjacent lanes of one value and a few
+    // butterfly steps finish the 64-lane sum.  (With VPP = 8: 16 LDS accesses
     // and 6 cross-lane moves per lane instead of 12 cross-lane moves per value.)
-    u64 *slab = reinterpret_cast<u64 *>(lds_raw + BAND_LDS_WAVE + wave * wave_bytes);
-    u64 wsum[2] = {0, 0};  // lane l: wave total of value l>>3 (pass 0) and 8 + (l>>3) (pass 1)
+    unsigned char *slab_raw = CONTOUR ? lds_raw + BAND_LDS_WAVE + FX_WAVES_PER_BLOCK * wave_bytes + BAND_TAB_BYTES + wave * BAND_CSLAB_BYTES
+                                      : lds_raw + BAND_LDS_WAVE + wave * wave_bytes;
+    u64 *slab = reinterpret_cast<u64 *>(slab_raw);
+    // contour variant: 4 values per pass in a 2 KiB slab (LDS per block decides how many blocks a CU holds)
+    constexpr int VPP = CONTOUR ? BAND_VPP_CONTOUR : 8;
+    constexpr int LPV = FX_WAVE / VPP;  // lanes that share one value after the column sums
+    constexpr int PASSES = (NV + VPP - 1) / VPP;
+    u64 wsum[PASSES];  // lane l: wave total of value pass * VPP + l / LPV
 #pragma unroll
-    for (int pass = 0; pass < (NV + 7) / 8; pass++) {
+    for (int pass = 0; pass < PASSES; pass++) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int k = 0; k < 8; k++)
-            slab[k * FX_WAVE + lane] = (pass * 8 + k < NV) ? V[(pass * 8 + k < NV) ? pass * 8 + k : 0] : 0ull;
+        for (int k = 0; k < VPP; k++)
+            slab[k * FX_WAVE + lane] = (pass * VPP + k < NV) ? V[(pass * VPP + k < NV) ? pass * VPP + k : 0] : 0ull;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         u64 acc = 0;
-        const u64 *col = slab + (lane >> 3) * FX_WAVE + (lane & 7) * 8;
+        const u64 *col = slab + (lane / LPV) * FX_WAVE + (lane % LPV) * VPP;
 #pragma unroll
-        for (int i = 0; i < 8; i++)
+        for (int i = 0; i < VPP; i++)
             acc += col[i];
-        acc += (u64)__shfl_xor((unsigned long long)acc, 1, FX_WAVE);
-        acc += (u64)__shfl_xor((unsigned long long)acc, 2, FX_WAVE);
-        acc += (u64)__shfl_xor((unsigned long long)acc, 4, FX_WAVE);
+#pragma unroll
+        for (int o = 1; o < LPV; o <<= 1)
+            acc += (u64)__shfl_xor((unsigned long long)acc, o, FX_WAVE);
         wsum[pass] = acc;
     }
     // Block level: 4 waves x 16 values through `red`.
-    if ((lane & 7) == 0) {
-        red[wave * BAND_SUMS + (lane >> 3)] = wsum[0];
-        red[wave * BAND_SUMS + 8 + (lane >> 3)] = wsum[1];
+    if (lane % LPV == 0) {
+#pragma unroll
+        for (int pass = 0; pass < PASSES; pass++)
+            if (pass * VPP + lane / LPV < BAND_SUMS)
+                red[wave * BAND_SUMS + pass * VPP + lane / LPV] = wsum[pass];
     }
     __syncthreads();
     if (t < NV) {
@@ -975,6 +1162,8 @@ __global__ __launch_bounds__(FX_BLOCK, FX_BAND_WAVES) void hu_band_kernel(HuArgs
             sum += red[w * BAND_SUMS + t];
         G.sums[b * BAND_SUMS + t] = sum;
     }
+    if (CONTOUR)
+        band_contour_hist(A, b, lds_raw, reinterpret_cast<uint32_t *>(lds_raw + BAND_LDS_WAVE + wave * wave_bytes), qn);
 }
 
 // One lane per image: everything that is serial float64 arithmetic.
@@ -1026,11 +1215,6 @@ __global__ __launch_bounds__(FX_BLOCK) void hu_finalize_kernel(HuArgs A, BandScr
             A.ceig[b * 6 + 3 + i] = v1[i];
         }
     }
-    double *p = G.params + b * 4;
-    p[0] = (double)sx / dn;
-    p[1] = (double)sy / dn;
-    p[2] = v1[0];
-    p[3] = v1[1];
 }
 
 // Tiled mode, one lane per image: shift every tile's local sums to image
@@ -1108,191 +1292,6 @@ __global__ __launch_bounds__(FX_BLOCK) void hu_from_partial_kernel(const int64_t
     }
     finalize_moments(raw, moments24 ? moments24 + b * 24 : nullptr, hu7 ? hu7 + b * 7 : nullptr,
                      hulog7 ? hulog7 + b * 7 : nullptr);
-}
-
-// One wave per image: largest |projection on PC1| over the contour pixels and
-// the histogram of it, from the queued segments.  Along a segment the signed
-// projection is monotone in x, so its largest magnitude is at an end, and a
-// segment whose two ends fall into the same bin on the same side of zero
-// belongs to that bin as a whole.
-__global__ __launch_bounds__(FX_BLOCK) void hu_contour_hist_kernel(HuArgs A, BandScratch G)
-{
-    __shared__ uint32_t hist_all[FX_WAVES_PER_BLOCK][64];
-    __shared__ uint32_t list_all[FX_WAVES_PER_BLOCK][16 * FX_WAVE];
-    const int lane = fx_lane(), wave = fx_wave();
-    const int64_t b = (int64_t)blockIdx.x * FX_WAVES_PER_BLOCK + wave;
-    if (b >= A.B)
-        return;  // waves are independent: no block barrier below
-    const u64 n = G.sums[b * BAND_SUMS + 10];
-    if (band_overflowed(G.qcount, b, A.qcap) || n < 3)
-        return;
-    const int wcap = A.qcap >> 2;
-    const uint32_t *qc = G.qcount + b * FX_WAVES_PER_BLOCK;
-    const int c0 = (int)qc[0], c1 = c0 + (int)qc[1], c2 = c1 + (int)qc[2], qn = c2 + (int)qc[3];
-    const int nb = A.n_bins;
-    uint32_t *hist = hist_all[wave];
-    hist[lane] = 0;
-    const double *p = G.params + b * 4;
-    const double ccx = p[0], ccy = p[1], vx = p[2], vy = p[3];
-    const uint32_t *gq = G.queue + b * FX_WAVES_PER_BLOCK * wcap;
-    // segment i of the image: the four per-wave parts one after the other
-    auto segment = [&](int i) -> uint32_t {
-        const int part = (i >= c0) + (i >= c1) + (i >= c2);
-        const int first = part == 0 ? 0 : part == 1 ? c0 : part == 2 ? c1 : c2;
-        return gq[part * wcap + (i - first)];
-    };
-
-    auto sproj = [&](uint32_t X, int i, double dyv) -> double {
-        return fma(dyv, vy, ((double)(int)(X + i) - ccx) * vx);
-    };
-
-    // The first KC * 64 segments (all of them for an ordinary shape) are loaded
-    // at once and kept in registers for both passes, so that the wave waits for
-    // memory once and not once per segment.
-    constexpr int KC = 16;
-    uint32_t ent[KC];
-#pragma unroll
-    for (int k = 0; k < KC; k++) {
-        const int i = lane + FX_WAVE * k;
-        ent[k] = i < qn ? segment(i) : 0u;
-    }
-
-    auto ends = [&](uint32_t e, double &slo, double &shi, int &lo, int &hi, uint32_t &X, double &dy) {
-        const uint32_t bits = e & 0xFFFFu, pos = e >> 16;
-        X = (pos & 63u) * 16u;
-        dy = (double)(int)(pos >> 6) - ccy;
-        lo = __ffs((int)bits) - 1;
-        hi = 31 - __clz((int)bits);
-        slo = sproj(X, lo, dy);
-        shi = sproj(X, hi, dy);
-    };
-    auto larger = [&](uint32_t e, double best) -> double {
-        double slo, shi, dy;
-        int lo, hi;
-        uint32_t X;
-        ends(e, slo, shi, lo, hi, X, dy);
-        return fmax(best, fmax(fabs(slo), fabs(shi)));
-    };
-    // The same two end values in float32.  They only sort out the segments whose
-    // answer is beyond doubt: everything within `eps` of a decision boundary is
-    // decided again in float64, so the results are those of the float64 formula.
-    const float cx32 = (float)ccx, cy32 = (float)ccy, vx32 = (float)vx, vy32 = (float)vy;
-    auto ends32 = [&](uint32_t e, float &slo, float &shi) {
-        const uint32_t bits = e & 0xFFFFu, pos = e >> 16;
-        const float xb = (float)(int)((pos & 63u) * 16u) - cx32;
-        const float t = ((float)(int)(pos >> 6) - cy32) * vy32;
-        const float lo = (float)(__ffs((int)bits) - 1), hi = (float)(31 - __clz((int)bits));
-        slo = fmaf(xb + lo, vx32, t);
-        shi = fmaf(xb + hi, vx32, t);
-    };
-
-    // Segments that float32 cannot settle are collected (ballot-compacted, so
-    // that the slower code below runs with full lanes) in the wave's LDS list.
-    uint32_t *list = list_all[wave];
-    uint32_t nl = 0;  // wave-uniform
-    auto defer = [&](bool want, uint32_t e) {
-        const unsigned long long m = __ballot(want);
-        if (m) {
-            const uint32_t at = nl + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (want)
-                list[at] = e;
-            nl += (uint32_t)__popcll(m);
-        }
-    };
-    auto list_ready = [&]() {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    };
-
-    float m32[KC];
-    float top32 = 0.0f;
-#pragma unroll
-    for (int k = 0; k < KC; k++) {
-        m32[k] = -1.0f;
-        if (FX_WAVE * k < qn && ent[k]) {
-            float a, c;
-            ends32(ent[k], a, c);
-            m32[k] = fmaxf(fabsf(a), fabsf(c));
-            top32 = fmaxf(top32, m32[k]);
-        }
-    }
-    double top = 0.0;
-    for (int i = lane + FX_WAVE * KC; i < qn; i += FX_WAVE)  // beyond the register cache: float64 directly
-        top = larger(segment(i), top);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-        top32 = fmaxf(top32, __shfl_xor(top32, o, FX_WAVE));
-    // float32 error bound of a projection (coordinates below 1024, |v| <= 1): a few 1e-4; eps is generous
-    const float eps = 4e-7f * (top32 + fabsf(cx32) + fabsf(cy32) + 1024.0f);
-#pragma unroll
-    for (int k = 0; k < KC; k++)
-        if (FX_WAVE * k < qn)
-            defer(m32[k] >= top32 - 2.0f * eps, ent[k]);  // the exact maximum is among these
-    list_ready();
-    for (uint32_t i = lane; i < nl; i += FX_WAVE)
-        top = larger(list[i], top);
-    top = fx_wave_max_f64(top);
-    list_ready();
-    nl = 0;
-
-    float *out = A.cpca + b * (9 + nb) + 9;
-    if (!(top > 0.0)) {
-        if (lane < nb)
-            out[lane] = lane == 0 ? 1.0f : 0.0f;
-        return;
-    }
-    const double step = top / (double)nb;
-    const double inv_step = (double)nb / top;
-    // float32 bin of |s|, or -1 when |s| / step is within `margin` of an integer
-    const float inv32 = (float)inv_step;
-    const float margin = 2.0f * eps * inv32 + 1e-5f * (float)nb;
-    auto bin32 = [&](float v) -> int {
-        const float q = fabsf(v) * inv32;
-        const float f = floorf(q);
-        const float frac = q - f;
-        if (frac < margin || frac > 1.0f - margin || q >= (float)nb)
-            return -1;
-        return (int)f;
-    };
-    // one pixel at a time: float32 where it is certain, float64 otherwise
-    auto count_pixels = [&](uint32_t e) {
-        const uint32_t pos = e >> 16;
-        const uint32_t X = (pos & 63u) * 16u;
-        const float xb = (float)(int)X - cx32;
-        const float t32 = ((float)(int)(pos >> 6) - cy32) * vy32;
-        const double dy = (double)(int)(pos >> 6) - ccy;
-        uint32_t rest = e & 0xFFFFu;
-        while (rest) {
-            const int k = __ffs((int)rest) - 1;
-            rest &= rest - 1;
-            int bin = bin32(fmaf(xb + (float)k, vx32, t32));
-            if (bin < 0)
-                bin = fx_hist_bin(fabs(sproj(X, k, dy)), step, inv_step, nb);
-            atomicAdd(&hist[bin], 1u);
-        }
-    };
-#pragma unroll
-    for (int k = 0; k < KC; k++) {
-        if (FX_WAVE * k < qn) {
-            float a = 0.f, c = 0.f;
-            ends32(ent[k], a, c);
-            const int ba = bin32(a), bc = bin32(c);
-            const bool same_side = (a > eps && c > eps) || (a < -eps && c < -eps);
-            const bool whole = ent[k] && ba >= 0 && ba == bc && same_side;
-            if (whole)
-                atomicAdd(&hist[ba], (uint32_t)__popc(ent[k] & 0xFFFFu));
-            defer(ent[k] && !whole, ent[k]);
-        }
-    }
-    list_ready();
-    for (uint32_t i = lane; i < nl; i += FX_WAVE)
-        count_pixels(list[i]);
-    for (int i = lane + FX_WAVE * KC; i < qn; i += FX_WAVE)
-        count_pixels(segment(i));
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (lane < nb)
-        out[lane] = (float)((double)hist[lane] / (double)n);
 }
 
 __global__ void hu_groupstat_kernel(const float *hulog7, const int64_t *offsets, int64_t G, float *out14)
@@ -1468,8 +1467,6 @@ extern "C" int fx_hu_batch_u8(const uint8_t *d_img, int64_t B, int H, int W, int
         if (!G.sums)
             return FX_ENOMEM;
         G.qcount = nullptr;
-        G.queue = nullptr;
-        G.params = nullptr;
         G.redo_count = nullptr;
         G.redo_list = nullptr;
         int rc;
@@ -1492,28 +1489,31 @@ extern "C" int fx_hu_batch_u8(const uint8_t *d_img, int64_t B, int H, int W, int
     const int64_t wave_segments = (int64_t)A.hb * A.bpw * A.cpr;
     A.qcap = (int)(wave_segments < 1024 ? wave_segments : 1024) * FX_WAVES_PER_BLOCK;
 
-    // per-launch scratch: sums | queue counts | contour parameters | queues
+    // per-launch scratch: sums | queue counts | redo list
     const size_t sums_bytes = (size_t)B * BAND_SUMS * sizeof(u64);
     const size_t count_bytes = (size_t)B * FX_WAVES_PER_BLOCK * 4;
     const size_t redo_bytes = contour ? 16 + (((size_t)B * 4 + 15) & ~(size_t)15) : 0;
-    const size_t param_bytes = contour ? (size_t)B * 4 * sizeof(double) : 0;
-    const size_t queue_bytes = contour ? (size_t)B * A.qcap * 4 : 0;
-    unsigned char *base = (unsigned char *)fx_scratch(sums_bytes + count_bytes + param_bytes + redo_bytes + queue_bytes, 1);
+    unsigned char *base = (unsigned char *)fx_scratch(sums_bytes + count_bytes + redo_bytes, 1);
     if (!base)
         return FX_ENOMEM;
     BandScratch G;
     G.sums = (u64 *)base;
     G.qcount = (uint32_t *)(base + sums_bytes);
-    G.params = (double *)(base + sums_bytes + count_bytes);
-    G.redo_count = (uint32_t *)(base + sums_bytes + count_bytes + param_bytes);
+    G.redo_count = (uint32_t *)(base + sums_bytes + count_bytes);
     G.redo_list = G.redo_count + 4;
-    G.queue = (uint32_t *)(base + sums_bytes + count_bytes + param_bytes + redo_bytes);
     const bool may_overflow = contour && (A.qcap >> 2) < wave_segments;
     if (may_overflow)
         FX_HIP_CHECK(hipMemsetAsync(G.redo_count, 0, 16, s));
 
     A.wave_lds = contour && A.qcap > BAND_SLAB_BYTES ? A.qcap : BAND_SLAB_BYTES;  // qcap / 4 entries of 4 bytes
-    const size_t band_lds = (size_t)BAND_LDS_WAVE + (size_t)FX_WAVES_PER_BLOCK * A.wave_lds + BAND_TAB_BYTES;
+    size_t band_lds = (size_t)BAND_LDS_WAVE + (size_t)FX_WAVES_PER_BLOCK * A.wave_lds + BAND_TAB_BYTES +
+                            (contour ? FX_WAVES_PER_BLOCK * BAND_CSLAB_BYTES : 0);
+    // Blocks per CU follow from the LDS a block asks for: 31 KiB lets five in.  Bands of 64 rows and more
+    // stream long enough that four blocks per CU keep the memory system busy, and measure 2 % faster than
+    // five (fewer concurrent streams); shorter bands want the fifth block to cover the histogram tails.
+    const size_t four_per_cu = 33 * 1024;
+    if (contour && A.hb >= 64 && band_lds < four_per_cu)
+        band_lds = four_per_cu;
     int rc;
     {
         FxProfileScope prof(s);
@@ -1526,9 +1526,6 @@ extern "C" int fx_hu_batch_u8(const uint8_t *d_img, int64_t B, int H, int W, int
     FX_HIP_CHECK(hipGetLastError());
     if (!contour)
         return FX_OK;
-    hipLaunchKernelGGL(hu_contour_hist_kernel, dim3((unsigned)((B + FX_WAVES_PER_BLOCK - 1) / FX_WAVES_PER_BLOCK)),
-                       dim3(FX_BLOCK), 0, s, A, G);
-    FX_HIP_CHECK(hipGetLastError());
     if (may_overflow) {
         // images whose contour queue overflowed (very ragged masks) go through the mask kernel
         A.redo_count = G.redo_count;

@@ -1,0 +1,76 @@
+"""Turns rocprofv3 output directories into the summaries kept under profiles/.
+
+Run on the GPU box after the rocprofv3 passes of tools/collect_profiles.sh:
+    python3 tools/collect_profiles.py <workload> <out_dir> <round_dir>
+reads  <out_dir>/stats/**/*kernel_stats.csv, <out_dir>/fetch/**/*counter_collection.csv and
+<out_dir>/write/**/*counter_collection.csv, writes <round_dir>/<workload>_kernel_stats.csv and
+<round_dir>/<workload>_pmc_hbm.json and updates profiles/traffic.json.
+"""
+import csv
+import json
+import re
+import sys
+from collections import defaultdict
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+DOMINANT = {"c3": "hu_band_kernel", "c2": "hu_band_kernel", "c4": "pca_sets_reg_kernel", "f1": "sil_mask_kernel"}
+UNITS = {"c3": (125000, 262144), "c2": (250000, 65536), "c4": (1000000, 12288), "f1": (20000, 50176)}
+
+
+def short(name):
+    m = re.search(r"(\w+_kernel)", name)
+    return m.group(1) if m else name
+
+
+def counter_means(folder):
+    """kernel -> mean counter value per launch."""
+    per_dispatch = defaultdict(float)  # a dispatch may have one row per counter instance
+    for f in Path(folder).rglob("*counter_collection.csv"):
+        with open(f, newline="") as fh:
+            for row in csv.DictReader(fh):
+                per_dispatch[(short(row["Kernel_Name"]), row["Dispatch_Id"])] += float(row["Counter_Value"])
+    tot, cnt = defaultdict(float), defaultdict(int)
+    for (k, _), v in per_dispatch.items():
+        tot[k] += v
+        cnt[k] += 1
+    return {k: tot[k] / cnt[k] for k in tot}
+
+
+def main():
+    workload, out_dir, round_dir = sys.argv[1], Path(sys.argv[2]), Path(sys.argv[3])
+    round_dir.mkdir(parents=True, exist_ok=True)
+    stats = sorted((out_dir / "stats").rglob("*kernel_stats.csv"))
+    if stats:
+        rows = list(csv.DictReader(open(stats[0], newline="")))
+        with open(round_dir / f"{workload}_kernel_stats.csv", "w", newline="") as fh:
+            w = csv.writer(fh)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+            for r in rows:
+                w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
+                            r["MinNs"], r["MaxNs"]])
+    fetch, write = counter_means(out_dir / "fetch"), counter_means(out_dir / "write")
+    if not fetch:
+        return
+    kernels = {k: {"FETCH_SIZE": fetch.get(k, 0.0), "WRITE_SIZE": write.get(k, 0.0)} for k in fetch if k.endswith("_kernel")}
+    dom = DOMINANT[workload]
+    units, bytes_per_unit = UNITS[workload]
+    hbm = 2.0 * kernels[dom]["FETCH_SIZE"] * 1024.0 + kernels[dom]["WRITE_SIZE"] * 1024.0
+    doc = {
+        "command": "rocprofv3 --pmc <COUNTER> --output-format csv -- python3 bench.py --workload %s --steps 3 --warmup 1 "
+                   "--no-cpu-baseline (one counter per run)" % workload,
+        "note": "FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts half of the bytes of a 16 B/lane "
+                "coalesced streaming read, so read bytes = 2 * FETCH_SIZE * 1024",
+        "kernels": kernels,
+        dom + "_hbm_bytes_per_launch": hbm,
+        "algorithmic_bytes_per_launch": units * bytes_per_unit,
+    }
+    (round_dir / f"{workload}_pmc_hbm.json").write_text(json.dumps(doc, indent=1))
+    tfile = ROOT / "profiles" / "traffic.json"
+    traffic = json.loads(tfile.read_text()) if tfile.exists() else {}
+    traffic[workload] = {"hbm_bytes_per_launch": hbm, "source": f"{round_dir}/{workload}_pmc_hbm.json", "units_per_launch": units}
+    tfile.write_text(json.dumps(traffic, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main()
