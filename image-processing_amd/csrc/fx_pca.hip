@@ -318,15 +318,20 @@ __device__ __forceinline__ void wave_sum9(double (&v)[9], double *slab)
         v[k] = tot[k];
 }
 
-template <int PPL, bool FULL>
-__global__ __launch_bounds__(FX_BLOCK, FX_PCA_WAVES) void pca_sets_reg_kernel(PcaArgs A)
+#ifndef FX_PCA_NW
+#define FX_PCA_NW 4
+#endif
+template <int PPL, bool FULL, int NW>
+__global__ __launch_bounds__(FX_WAVE *NW, FX_PCA_WAVES) void pca_sets_reg_kernel(PcaArgs A)
 {
-    __shared__ uint32_t hist_all[FX_WAVES_PER_BLOCK][HIST_MAX];
-    __shared__ double red_all[FX_WAVES_PER_BLOCK][RED9_WORDS];
+    __shared__ uint32_t hist_all[NW][HIST_MAX];
+    __shared__ double red_all[NW][RED9_WORDS];
+    __shared__ double cov_all[NW][6], eig_all[NW][6];
     const int lane = fx_lane(), wave = fx_wave();
-    const int64_t set = (int64_t)blockIdx.x * FX_WAVES_PER_BLOCK + wave;
-    if (set >= A.n_sets)
-        return;  // whole wave leaves; no block-level barrier is used below
+    const int64_t set_raw = (int64_t)blockIdx.x * NW + wave;
+    // a wave past the last set stays for the block barriers: it works on set 0 and writes nothing
+    const bool live = set_raw < A.n_sets;
+    const int64_t set = live ? set_raw : 0;
     const int n = (int)A.N;
     uint32_t *hist = hist_all[wave];
     hist[lane] = 0;
@@ -408,11 +413,35 @@ __global__ __launch_bounds__(FX_BLOCK, FX_PCA_WAVES) void pca_sets_reg_kernel(Pc
             S[k] *= w;
     }
 
-    // every lane holds the same sums and runs the same eigen-solve
+    // The eigen-solve is serial code: one wave of the block runs it for all NW
+    // sets of the block at once, a lane per set, instead of every wave running
+    // it on 64 identical lanes.  The duty rotates over the waves with the block
+    // index, so that it does not pile up on one SIMD.
     double lam[3], v1[3];
     {
         const double inv = 1.0 / (double)(n - 1);  // np.cov multiplies by 1/(n-1)
-        fx_eig3<true>(S[0] * inv, S[1] * inv, S[2] * inv, S[3] * inv, S[4] * inv, S[5] * inv, lam, v1);
+        if (lane < 6) {
+            double c = S[0];
+            c = lane == 1 ? S[1] : c;
+            c = lane == 2 ? S[2] : c;
+            c = lane == 3 ? S[3] : c;
+            c = lane == 4 ? S[4] : c;
+            c = lane == 5 ? S[5] : c;
+            cov_all[wave][lane] = c * inv;
+        }
+        __syncthreads();
+        if (wave == (int)(blockIdx.x % NW) && lane < NW) {
+            const double *c = cov_all[lane];
+            double l3[3], w3[3];
+            fx_eig3<true>(c[0], c[1], c[2], c[3], c[4], c[5], l3, w3);
+            double *e = eig_all[lane];
+            e[0] = l3[0], e[1] = l3[1], e[2] = l3[2];
+            e[3] = w3[0], e[4] = w3[1], e[5] = w3[2];
+        }
+        __syncthreads();
+        const double *e = eig_all[wave];
+        lam[0] = e[0], lam[1] = e[1], lam[2] = e[2];
+        v1[0] = e[3], v1[1] = e[4], v1[2] = e[5];
     }
     // the nine scalars (fx_pca_head), lane k computing entry k: one division
     // per lane instead of five one after the other
@@ -489,16 +518,16 @@ __global__ __launch_bounds__(FX_BLOCK, FX_PCA_WAVES) void pca_sets_reg_kernel(Pc
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (lane < nb)
+        if (live && lane < nb)
             // count / n: both are integers below 2^24, so the float32 quotient is the
             // float64 quotient rounded to float32
             A.out[set * width + 9 + lane] = (float)hist[lane] / (float)n;
-    } else if (lane < nb) {
+    } else if (live && lane < nb) {
         A.out[set * width + 9 + lane] = lane == 0 ? 1.0f : 0.0f;
     }
-    if (lane < 9)
+    if (live && lane < 9)
         A.out[set * width + lane] = (float)head_mine;
-    if (A.eig && lane < 6) {
+    if (live && A.eig && lane < 6) {
         double e = lam[0];
         e = lane == 1 ? lam[1] : e;
         e = lane == 2 ? lam[2] : e;
@@ -912,13 +941,14 @@ extern "C" int fx_pca_batch_f32(const float *d_pts, const int64_t *d_offsets, in
         const bool reg_ok = dims == 3 && N >= 4 && N <= 1024 && N % 4 == 0 && (uintptr_t)d_pts % 16 == 0 &&
                             !(force && strcmp(force, "lds") == 0);
         if (reg_ok) {
-            const dim3 grid((unsigned)((B + FX_WAVES_PER_BLOCK - 1) / FX_WAVES_PER_BLOCK)), block(FX_BLOCK);
+            constexpr int NW = FX_PCA_NW;  // sets (waves) per block
+            const dim3 grid((unsigned)((B + NW - 1) / NW)), block(FX_WAVE * NW);
             if (N <= 256)
-                hipLaunchKernelGGL((pca_sets_reg_kernel<4, false>), grid, block, 0, s, A);
+                hipLaunchKernelGGL((pca_sets_reg_kernel<4, false, NW>), grid, block, 0, s, A);
             else if (N <= 512)
-                hipLaunchKernelGGL((pca_sets_reg_kernel<8, false>), grid, block, 0, s, A);
+                hipLaunchKernelGGL((pca_sets_reg_kernel<8, false, NW>), grid, block, 0, s, A);
             else
-                hipLaunchKernelGGL((pca_sets_reg_kernel<16, false>), grid, block, 0, s, A);
+                hipLaunchKernelGGL((pca_sets_reg_kernel<16, false, NW>), grid, block, 0, s, A);
             FX_HIP_CHECK(hipGetLastError());
             return FX_OK;
         }
