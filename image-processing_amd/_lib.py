@@ -42,6 +42,9 @@ SIGNATURES = {
     "fx_read_npy_points_f32": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_int]),
     "fx_write_npy_rows_f32": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int]),
     "fx_decode_png_gray_u8": (c_int, [c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int]),
+    "fx_column_thresholds_f64": (c_int, [c_void_p, c_i64, c_int, c_i64, c_void_p, c_int, c_int, ctypes.c_double, c_int,
+                                         c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fx_binarize_ge_f64": (c_int, [c_void_p, c_i64, c_int, c_i64, c_void_p, c_void_p, c_void_p]),
     "fx_synth_shapes_u8": (c_int, [c_void_p, c_i64, c_int, c_int, c_i64, c_i64, c_u64, c_i64, c_void_p]),
     "fx_synth_points_f32": (c_int, [c_void_p, c_i64, c_i64, c_u64, c_i64, c_void_p]),
     "fx_profile": (c_int, [c_int]),
@@ -69,6 +72,9 @@ def load() -> ctypes.CDLL:
         raise ImportError(
             f"{LIB_PATH} not found: build it with `make -C {_HERE / 'csrc'}` "
             "(or __graft_entry__.build()); this package has no CPU fallback")
+    # torch brings its own HIP runtime: it has to be in the process before libfx.so is, so that both
+    # resolve to the same one (with the system's runtime loaded first, libfx then finds no device)
+    import torch  # noqa: F401
     lib = ctypes.CDLL(str(LIB_PATH))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol

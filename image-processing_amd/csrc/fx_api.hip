@@ -7,7 +7,7 @@
 namespace {
 
 constexpr int kMaxDevices = 16;
-constexpr int kScratchSlots = 6;
+constexpr int kScratchSlots = 7;
 
 thread_local char g_err[512] = "";
 

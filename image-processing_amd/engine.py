@@ -272,6 +272,51 @@ def fps(points: torch.Tensor, offsets, n_samples: int, start, *, gather: bool = 
     return out
 
 
+def column_thresholds(x: torch.Tensor, method: str = "median", quantile: float = 0.5, *, labels: Optional[torch.Tensor] = None,
+                      label: int = 0, constant_rule: bool = True) -> dict:
+    """Per-column thresholds of a float64 table [rows, cols] on the device
+    (reference fit_thresholds' col_thresh, src/models/train_bernoulli_nb.py:348-364).
+    `labels` (int32 [rows]) with `label` restricts the rows to one class.
+    Returns {"thr": f64 [cols], "flags": int32 [cols] (1 constant, 2 NaN), "count": rows used}."""
+    _require_cuda(x, "x")
+    if x.dim() != 2 or x.dtype != torch.float64 or x.shape[1] < 1 or (x.shape[0] > 1 and x.stride(1) != 1):
+        raise ValueError("x must be float64 [rows, cols] with unit column stride")
+    code = {"median": 0, "quantile": 1, "otsu": 2}.get(method)
+    if code is None:
+        raise ValueError("Unknown binarize method")
+    if labels is not None:
+        _require_cuda(labels, "labels")
+        if labels.dtype != torch.int32 or labels.shape != (x.shape[0],) or not labels.is_contiguous():
+            raise ValueError("labels must be contiguous int32 [rows]")
+    stream = _enter(x.device)
+    rows, cols = int(x.shape[0]), int(x.shape[1])
+    thr = torch.empty(cols, dtype=torch.float64, device=x.device)
+    flags = torch.empty(cols, dtype=torch.int32, device=x.device)
+    count = torch.zeros(1, dtype=torch.int64, device=x.device)
+    _lib.call("fx_column_thresholds_f64", x.data_ptr(), rows, cols, x.stride(0) if rows > 1 else cols, _ptr(labels),
+              int(label), code, float(quantile), 1 if constant_rule else 0, thr.data_ptr(), flags.data_ptr(),
+              count.data_ptr(), stream)
+    return {"thr": thr, "flags": flags, "count": count}
+
+
+def binarize_ge(x: torch.Tensor, thr: torch.Tensor) -> torch.Tensor:
+    """uint8 [rows, cols] = x >= thr per column (reference apply_thresholds,
+    src/models/train_bernoulli_nb.py:379-385)."""
+    _require_cuda(x, "x")
+    _require_cuda(thr, "thr")
+    if x.dim() != 2 or x.dtype != torch.float64 or (x.shape[0] > 1 and x.stride(1) != 1):
+        raise ValueError("x must be float64 [rows, cols] with unit column stride")
+    if thr.dtype != torch.float64 or thr.shape != (x.shape[1],) or not thr.is_contiguous():
+        raise ValueError("thr must be contiguous float64 [cols]")
+    stream = _enter(x.device)
+    rows, cols = int(x.shape[0]), int(x.shape[1])
+    out = torch.empty((rows, cols), dtype=torch.uint8, device=x.device)
+    if rows and cols:
+        _lib.call("fx_binarize_ge_f64", x.data_ptr(), rows, cols, x.stride(0) if rows > 1 else cols, thr.data_ptr(),
+                  out.data_ptr(), stream)
+    return out
+
+
 def synth_shapes(B: int, H: int, W: int, seed: int = 42, first_index: int = 0, device="cuda",
                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """B synthetic {0,255} shape images generated on the device."""

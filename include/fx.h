@@ -275,6 +275,34 @@ int fx_decode_png_gray_u8(const char *const *paths, int64_t n, int H, int W,
                           int n_threads);
 
 /*
+ * Per-column binarisation thresholds of a feature table: fit_thresholds,
+ * src/models/train_bernoulli_nb.py:331-376 (col_thresh :348-356 = np.median /
+ * np.quantile / _otsu_threshold_1d :307-328, its NumPy histogram branch).
+ * d_x: rows x cols float64, row_stride elements between rows (device memory).
+ * d_labels (or NULL) with `label` restricts the rows to one class, as the
+ * "per_class" strategy does (:366-374); the mean over classes is the caller's.
+ * method: 0 median, 1 quantile q (NumPy's default linear interpolation),
+ * 2 Otsu.  constant_rule != 0: a column whose values all equal its first value
+ * gets that value (:360-364).  d_thr[cols]; d_flags[cols] (optional): bit 0 =
+ * constant column, bit 1 = the column holds NaN (its threshold is NaN, as
+ * np.median gives); d_count[1] (optional): rows that took part.
+ * Exact: order statistics by radix select, float64 arithmetic in NumPy's order.
+ */
+int fx_column_thresholds_f64(const double *d_x, int64_t rows, int cols,
+                             int64_t row_stride, const int32_t *d_labels,
+                             int label, int method, double q, int constant_rule,
+                             double *d_thr, int32_t *d_flags, int64_t *d_count,
+                             void *stream);
+
+/*
+ * apply_thresholds, src/models/train_bernoulli_nb.py:379-385:
+ * d_out[r, c] = d_x[r, c] >= d_thr[c] as uint8 (rows x cols, dense).
+ */
+int fx_binarize_ge_f64(const double *d_x, int64_t rows, int cols,
+                       int64_t row_stride, const double *d_thr, uint8_t *d_out,
+                       void *stream);
+
+/*
  * Synthetic inputs for benchmarks and parity tests (no reference counterpart:
  * the reference reads rendered PNG views and sampled .npy clouds from disk).
  * Image `first_index + b` / set `first_index + b` depends only on (seed, that

@@ -464,6 +464,68 @@ def build_c_oracle(force: bool = False) -> Path:
     return so
 
 
+# ---- feature binarisation thresholds (reference src/models/train_bernoulli_nb.py:307-385) ----
+
+def otsu_threshold_1d(values: np.ndarray) -> float:
+    """_otsu_threshold_1d :307-328, the NumPy branch (scikit-image is absent
+    where the reference ran here): 256-bin histogram, cumulative class weight
+    and mean, first maximum of the between-class variance, centre of that bin."""
+    if values.size == 0:
+        return 0.0
+    vals = values.astype(float)
+    hist, edges = np.histogram(vals, bins=256)
+    hist = hist.astype(float)
+    p = hist / hist.sum() if hist.sum() > 0 else hist
+    omega = np.cumsum(p)
+    mu = np.cumsum(p * ((edges[:-1] + edges[1:]) / 2.0))
+    mu_t = mu[-1] if len(mu) else 0.0
+    sigma = (mu_t * omega - mu) ** 2 / (omega * (1 - omega) + 1e-12)
+    idx = int(np.nanargmax(sigma)) if sigma.size else 0
+    return float((edges[idx] + edges[idx + 1]) / 2.0 if idx + 1 < len(edges) else edges[idx])
+
+
+def column_threshold(values: np.ndarray, method: str, quantile: float) -> float:
+    """col_thresh :348-356."""
+    if method == "median":
+        return float(np.median(values))
+    if method == "quantile":
+        return float(np.quantile(values, quantile))
+    if method == "otsu":
+        return otsu_threshold_1d(values)
+    raise ValueError("Unknown binarize method")
+
+
+def fit_thresholds(table: np.ndarray, y, method: str = "median", quantile: float = 0.5,
+                   strategy: str = "global") -> np.ndarray:
+    """fit_thresholds :331-376 on a float64 table [rows, cols] (the feature
+    columns of X_train in order) and the labels y: float64 [cols]."""
+    assert strategy in {"global", "per_class"}
+    table = np.asarray(table, dtype=float)
+    y = np.asarray(y)
+    out = np.empty(table.shape[1], dtype=np.float64)
+    for c in range(table.shape[1]):
+        values = table[:, c]
+        if np.all(values == values[0]):
+            out[c] = float(values[0])
+            continue
+        if strategy == "global":
+            out[c] = column_threshold(values, method, quantile)
+            continue
+        per_class = []
+        for cls in sorted(set(y.tolist())):
+            cls_vals = values[y == cls]
+            if cls_vals.size == 0:
+                continue
+            per_class.append(column_threshold(cls_vals, method, quantile))
+        out[c] = float(np.mean(per_class)) if per_class else column_threshold(values, method, quantile)
+    return out
+
+
+def apply_thresholds(table: np.ndarray, thr: np.ndarray) -> np.ndarray:
+    """apply_thresholds :379-385."""
+    return (np.asarray(table, dtype=float) >= np.asarray(thr, dtype=float)).astype(np.uint8)
+
+
 class COracle:
     """ctypes view of libfx_oracle.so."""
 

@@ -192,6 +192,48 @@ def make_fps(ref: Path) -> None:
     print(f"fps_golden.npz: {len(specs)} cases")
 
 
+def make_thresholds(ref: Path) -> None:
+    """Outputs of the reference's own fit_thresholds / apply_thresholds
+    (src/models/train_bernoulli_nb.py) on seeded feature tables: float32-valued
+    features as the extraction writes them, odd and even row counts, ties,
+    a constant column, a column of two values, every method and both strategies."""
+    import pandas as pd
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, str(ref / "src" / "models"))
+    mod = importlib.import_module("train_bernoulli_nb")
+    logging_off = __import__("logging")
+    logging_off.disable(logging_off.CRITICAL)
+    rng = np.random.default_rng(20251112)
+    out = {}
+    specs = [(11, 4, 3), (12, 5, 2), (200, 31, 7), (201, 31, 7), (57, 6, 4), (2, 3, 2), (1, 3, 1), (1000, 8, 5)]
+    k = 0
+    for si, (rows, cols, ncls) in enumerate(specs):
+        t = (rng.normal(size=(rows, cols)) * np.exp(rng.uniform(-3, 3, size=cols)) + rng.normal(size=cols) * 5)
+        t = t.astype(np.float32).astype(np.float64)
+        if cols >= 4:
+            t[:, 1] = 2.5                                   # constant column
+            t[:, 2] = rng.integers(0, 2, rows)              # two values: ties everywhere
+            t[:, 3] = np.round(t[:, 3], 1)                  # many ties
+        y = rng.integers(0, ncls, rows)
+        names = [f"f{c}" for c in range(cols)]
+        X = pd.DataFrame(t, columns=names)
+        X.insert(0, "id", [f"s{r}" for r in range(rows)])
+        ys = pd.Series(y)
+        for method, q in (("median", 0.5), ("quantile", 0.5), ("quantile", 0.3), ("quantile", 0.95), ("otsu", 0.5)):
+            for strategy in ("global", "per_class"):
+                thr = mod.fit_thresholds(X, ys, method=method, quantile=q, strategy=strategy)
+                vec = np.array([thr[c] for c in names], dtype=np.float64)
+                out[f"table_{si}"] = t
+                out[f"y_{si}"] = y.astype(np.int64)
+                out[f"thr_{k}"] = vec
+                out[f"bin_{k}"] = np.packbits(mod.apply_thresholds(X, thr), axis=1)
+                out[f"meta_{k}"] = np.array([method, strategy, repr(q), str(si)])
+                k += 1
+    out["n_cases"] = np.array(k)
+    np.savez_compressed(HERE / "thresholds_golden.npz", **out)
+    print(f"thresholds_golden.npz: {k} cases")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default=os.environ.get("FX_REFERENCE", "/root/reference"))
@@ -200,3 +242,4 @@ if __name__ == "__main__":
     make_hu(Path(a.reference))
     make_preprocess(Path(a.reference))
     make_fps(Path(a.reference))
+    make_thresholds(Path(a.reference))

@@ -170,3 +170,25 @@ def test_fps_restatement_equals_reference_outputs(oracle):
         np.testing.assert_array_equal(cen, g[f"cen_{k}"])
         rng = np.random.RandomState(seed) if seed >= 0 else None
         np.testing.assert_array_equal(oracle.farthest_point_sampling(norm, n, rng), g[f"idx_{k}"])
+
+
+# ------------------------------------------------------------ binarisation thresholds
+def threshold_cases():
+    g = np.load(GOLDEN / "thresholds_golden.npz")
+    for k in range(int(g["n_cases"])):
+        method, strategy, q, si = (str(v) for v in g[f"meta_{k}"])
+        table = g[f"table_{si}"]
+        bits = np.unpackbits(g[f"bin_{k}"], axis=1)[:, :table.shape[1]]
+        yield k, table, g[f"y_{si}"], method, strategy, float(q), g[f"thr_{k}"], bits
+
+
+def test_thresholds_restatement_equals_reference_outputs(oracle):
+    """thresholds_golden.npz holds outputs of the reference's fit_thresholds /
+    apply_thresholds (median, quantile, Otsu; global and per class)."""
+    n = 0
+    for k, table, y, method, strategy, q, thr, bits in threshold_cases():
+        got = oracle.fit_thresholds(table, y, method, q, strategy)
+        np.testing.assert_array_equal(got, thr, err_msg=f"case {k}: {method}/{strategy}/{q}")
+        np.testing.assert_array_equal(oracle.apply_thresholds(table, thr), bits)
+        n += 1
+    assert n == 80

@@ -110,6 +110,22 @@ if __name__ == "__main__":
         for (B,M,n) in [(4000,2048,1024),(2000,8192,1024),(512,16384,1024),(64,100000,1024)]:
             cs, fp = time_fps(B,M,n)
             print(f"fps B={B} M={M} n={n}: center_scale {cs:.3f} ms ({B*M*12/cs/1e6:.0f} GB/s)  fps {fp:.3f} ms  {B/fp*1e3:.0f} clouds/s  {B*M*n/fp/1e6:.1f} G point-updates/s", flush=True)
+    elif what == "bin":
+        import numpy as np
+        for rows, cols in ((1000000, 31), (100000, 31)):
+            x = torch.randn((rows, cols), dtype=torch.float64, device=dev)
+            for method in ("median", "quantile", "otsu"):
+                eng.column_thresholds(x, method, 0.3); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(5): eng.column_thresholds(x, method, 0.3)
+                torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5 * 1e3
+                print(f"thresholds {rows}x{cols} {method}: {dt:.3f} ms", flush=True)
+            thr = eng.column_thresholds(x)["thr"]
+            eng.binarize_ge(x, thr); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5): eng.binarize_ge(x, thr)
+            torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5 * 1e3
+            print(f"binarize {rows}x{cols}: {dt:.3f} ms  {rows*cols*9/dt/1e6:.0f} GB/s", flush=True)
     elif what == "sil1":
         ms, gbps = time_sil(20000, 224, 224, 224, reps=3)
         print(f"sil B=20000 224x224->224: {ms:.3f} ms  {gbps:.0f} GB/s", flush=True)
