@@ -78,6 +78,48 @@ __device__ __forceinline__ double fx_wave_max_f64(double v)
     return v;
 }
 
+// Wave-wide maximum through DPP row operations (a few cycles each) instead of
+// LDS-routed shuffles: pairs, quads, half rows, rows of 16, then the last lane
+// of a row broadcast into the next rows; lane 63 ends with the result, which
+// every lane receives as a wave-uniform value.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float fx_dpp_f32(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double fx_dpp_f64(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = (int)b, hi = (int)(b >> 32);
+    const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    return __longlong_as_double(((long long)hi2 << 32) | (unsigned int)lo2);
+}
+__device__ __forceinline__ float fx_wave_max_f32_dpp(float v)
+{
+    v = fmaxf(v, fx_dpp_f32<0xB1, 0xf>(v));   // quad_perm [1,0,3,2]
+    v = fmaxf(v, fx_dpp_f32<0x4E, 0xf>(v));   // quad_perm [2,3,0,1]
+    v = fmaxf(v, fx_dpp_f32<0x141, 0xf>(v));  // row_half_mirror
+    v = fmaxf(v, fx_dpp_f32<0x140, 0xf>(v));  // row_mirror
+    v = fmaxf(v, fx_dpp_f32<0x142, 0xa>(v));  // row_bcast:15 into rows 1 and 3
+    v = fmaxf(v, fx_dpp_f32<0x143, 0xc>(v));  // row_bcast:31 into rows 2 and 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ double fx_wave_max_f64_dpp(double v)
+{
+    v = fmax(v, fx_dpp_f64<0xB1, 0xf>(v));
+    v = fmax(v, fx_dpp_f64<0x4E, 0xf>(v));
+    v = fmax(v, fx_dpp_f64<0x141, 0xf>(v));
+    v = fmax(v, fx_dpp_f64<0x140, 0xf>(v));
+    v = fmax(v, fx_dpp_f64<0x142, 0xa>(v));
+    v = fmax(v, fx_dpp_f64<0x143, 0xc>(v));
+    const long long b = __double_as_longlong(v);
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)b, 63);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // Round an unsigned 128-bit integer (hi:lo) to the nearest double, ties to
 // even.
 __device__ __forceinline__ double fx_u128_to_double(u64 hi, u64 lo)

@@ -764,9 +764,7 @@ __device__ __forceinline__ void band_contour_hist(const HuArgs &A, const int64_t
         ends32(wq[i], a, c);
         top32 = fmaxf(top32, fmaxf(fabsf(a), fabsf(c)));
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-        top32 = fmaxf(top32, __shfl_xor(top32, o, FX_WAVE));
+    top32 = fx_wave_max_f32_dpp(top32);
     // float32 error bound of a projection (coordinates below 1024, |v| <= 1): a few 1e-4; the factor is generous
     const float eps_w = 4e-7f * (top32 + fabsf(cx32) + fabsf(cy32) + 1024.0f);
     // the wave's exact maximum is among the few segments within the error bound of the float32 one
@@ -778,7 +776,7 @@ __device__ __forceinline__ void band_contour_hist(const HuArgs &A, const int64_t
         if (fmaxf(fabsf(a), fabsf(c)) >= top32 - 2.0f * eps_w)
             top = larger(e, top);
     }
-    top = fx_wave_max_f64(top);
+    top = fx_wave_max_f64_dpp(top);
     if (lane == 0)
         bcast[wave] = top;
     __syncthreads();

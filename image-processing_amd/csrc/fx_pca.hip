@@ -352,7 +352,9 @@ __global__ __launch_bounds__(FX_WAVE *NW, FX_PCA_WAVES) void pca_sets_reg_kernel
         x[4 * k + 3] = c.y, y[4 * k + 3] = c.z, z[4 * k + 3] = c.w;
     }
     // pivot = the set's first point (lane 0, group 0)
-    const float kx32 = __shfl(x[0], 0, FX_WAVE), ky32 = __shfl(y[0], 0, FX_WAVE), kz32 = __shfl(z[0], 0, FX_WAVE);
+    const float kx32 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x[0])));
+    const float ky32 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(y[0])));
+    const float kz32 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(z[0])));
     const double kx = kx32, ky = ky32, kz = kz32;
 
     double D[3] = {0, 0, 0}, Q[6] = {0, 0, 0, 0, 0, 0};
@@ -403,7 +405,7 @@ __global__ __launch_bounds__(FX_WAVE *NW, FX_PCA_WAVES) void pca_sets_reg_kernel
                 r2 = fmax(r2, dx * dx + dy * dy + dz * dz);
             }
         }
-        rmax = sqrt(fx_wave_max_f64(r2));
+        rmax = sqrt(fx_wave_max_f64_dpp(r2));
     }
     const bool scale = A.normalize && rmax > 0.0;
     if (scale) {
@@ -482,16 +484,14 @@ __global__ __launch_bounds__(FX_WAVE *NW, FX_PCA_WAVES) void pca_sets_reg_kernel
         p32[i] = have[i >> 2] ? fabsf(fmaf(dz, vz32, fmaf(dy, vy32, dx * vx32))) : -1.0f;
         top32 = fmaxf(top32, p32[i]);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-        top32 = fmaxf(top32, __shfl_xor(top32, o, FX_WAVE));
+    top32 = fx_wave_max_f32_dpp(top32);
     const float eps32 = 2e-6f * (top32 + (fabsf(ox32) + fabsf(oy32) + fabsf(oz32)) * w32) + 1e-37f;
     double top = 0.0;
 #pragma unroll
     for (int i = 0; i < PPL; i++)
         if (p32[i] >= top32 - 2.0f * eps32)  // the exact maximum is among these
             top = fmax(top, proj(x[i], y[i], z[i]));
-    top = fx_wave_max_f64(top);
+    top = fx_wave_max_f64_dpp(top);
 
     const int nb = A.n_bins;
     const int width = 9 + nb;
