@@ -45,6 +45,9 @@ SIGNATURES = {
     "fx_column_thresholds_f64": (c_int, [c_void_p, c_i64, c_int, c_i64, c_void_p, c_int, c_int, ctypes.c_double, c_int,
                                          c_void_p, c_void_p, c_void_p, c_void_p]),
     "fx_binarize_ge_f64": (c_int, [c_void_p, c_i64, c_int, c_i64, c_void_p, c_void_p, c_void_p]),
+    "fx_cloud_bounds_f32": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
+    "fx_render_views_u8": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
+                                   c_void_p, c_void_p]),
     "fx_synth_shapes_u8": (c_int, [c_void_p, c_i64, c_int, c_int, c_i64, c_i64, c_u64, c_i64, c_void_p]),
     "fx_synth_points_f32": (c_int, [c_void_p, c_i64, c_i64, c_u64, c_i64, c_void_p]),
     "fx_profile": (c_int, [c_int]),

@@ -1,0 +1,262 @@
+// Multi-view renderer of point clouds: the reference's renderer without
+// Open3D / pyrender (src/preprocessing/render_views.py:294-366,
+// render_fallback_matplotlib), i.e. what matplotlib's Agg backend draws for
+//     ax.scatter(xs, ys, s=point_size, marker="o", linewidths=0)
+// on a resolution x resolution canvas with equal aspect and limits
+// [min - 1, max + 1]:
+//   * a point lands on the pixel (floor(px + 0.5), floor(res - py + 0.5)) of
+//     its display coordinates (Agg snaps marker positions to whole pixels);
+//   * every marker is the same small stamp of coverage values (rasterised once
+//     by Agg; the table of stamps per point size is host data);
+//   * markers are blended one after the other, in point order, with Agg's
+//     integer "plain" RGBA blend onto the opaque white figure, so a pixel's
+//     value depends on the order of the markers that touch it.
+// One block per (cloud, view): the canvas lives in LDS, the block projects and
+// snaps the points in parallel, and one wave applies the stamps in point
+// order, a lane per stamp cell (LDS operations of a wave complete in order).
+#include "fx_common.h"
+
+namespace {
+
+constexpr int RENDER_MAX_K = 7;        // stamps up to 7 x 7 cells (49 lanes of the stamping wave)
+constexpr int RENDER_CHUNK = 2048;     // snapped positions kept in LDS at a time
+constexpr int RENDER_MAX_RES = 384;    // canvas bytes in LDS: 384^2 = 144 KiB
+
+struct RenderArgs {
+    const float *pts;         // [total][3]
+    const int64_t *offsets;   // [B + 1], device
+    int64_t B;
+    int V;
+    const double *cam;        // [B][V][9]: right, true_up, look-at
+    const double *scale;      // [B]: (resolution * 0.35) / bbox diagonal
+    int res;
+    int K;
+    int marker;               // marker gray value: 0 on a white background, 255 on a black one
+    unsigned char stamp[RENDER_MAX_K * RENDER_MAX_K];
+    uint8_t *out;             // [B][V][res][res]
+};
+
+__device__ __forceinline__ double block_minmax(double v, bool is_max, double *red)
+{
+    v = is_max ? fx_wave_max_f64_dpp(v) : -fx_wave_max_f64_dpp(-v);
+    __syncthreads();
+    if (fx_lane() == 0)
+        red[fx_wave()] = v;
+    __syncthreads();
+    double r = red[0];
+#pragma unroll
+    for (int w = 1; w < FX_WAVES_PER_BLOCK; w++)
+        r = is_max ? fmax(r, red[w]) : fmin(r, red[w]);
+    return r;
+}
+
+// Agg's fixed_blender_rgba_plain::blend_pix for one channel of an opaque
+// pixel p, source value c, coverage-derived alpha a in 1..255:
+//   (((c << 8) - 255 p) a + ((255 p) << 8)) / (((a + 255) << 8) - 255 a)
+__device__ __forceinline__ uint32_t agg_blend(uint32_t p, uint32_t c, uint32_t a, uint32_t den, float inv_den)
+{
+    const uint32_t r = p * 255u;
+    const uint32_t num = ((c << 8) - r) * a + (r << 8);  // unsigned wrap-around cancels, the true value is below 2^24
+    uint32_t q = (uint32_t)((float)num * inv_den);
+    int32_t rem = (int32_t)(num - q * den);
+    if (rem < 0)
+        q -= 1;
+    else if (rem >= (int32_t)den)
+        q += 1;
+    return q;
+}
+
+__global__ __launch_bounds__(FX_BLOCK) void render_views_kernel(RenderArgs A)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    __shared__ double s_red[FX_WAVES_PER_BLOCK];
+    __shared__ uint32_t s_snap[RENDER_CHUNK];
+    uint8_t *canvas = lds_raw;
+    const int t = threadIdx.x;
+    const int64_t bv = blockIdx.x;
+    const int64_t b = bv / A.V;
+    const int res = A.res;
+    const int npx = res * res;
+    const int64_t lo = A.offsets[b], n = A.offsets[b + 1] - lo;
+    const float *pts = A.pts + lo * 3;
+    const double *cam = A.cam + bv * 9;
+    const double rx = cam[0], ry = cam[1], rz = cam[2], ux = cam[3], uy = cam[4], uz = cam[5];
+    const double cx = cam[6], cy = cam[7], cz = cam[8];
+    const double scale = A.scale[b];
+
+    for (int i = t * 4; i < npx; i += FX_BLOCK * 4) {
+        if (i + 4 <= npx)
+            *reinterpret_cast<uint32_t *>(canvas + i) = 0xFFFFFFFFu;
+        else
+            for (int k = i; k < npx; k++)
+                canvas[k] = 255;
+    }
+
+    // display-plane coordinates of a point, as the reference forms them
+    auto plane = [&](int64_t i, double &X, double &Y) {
+        const double dx = (double)pts[i * 3] - cx, dy = (double)pts[i * 3 + 1] - cy, dz = (double)pts[i * 3 + 2] - cz;
+        X = ((dx * rx + dy * ry) + dz * rz) * scale;
+        Y = ((dx * ux + dy * uy) + dz * uz) * scale;
+    };
+    const double inf = __builtin_inf();
+    double xmin = inf, xmax = -inf, ymin = inf, ymax = -inf;
+    for (int64_t i = t; i < n; i += FX_BLOCK) {
+        double X, Y;
+        plane(i, X, Y);
+        xmin = fmin(xmin, X), xmax = fmax(xmax, X);
+        ymin = fmin(ymin, Y), ymax = fmax(ymax, Y);
+    }
+    xmin = block_minmax(xmin, false, s_red);
+    xmax = block_minmax(xmax, true, s_red);
+    ymin = block_minmax(ymin, false, s_red);
+    ymax = block_minmax(ymax, true, s_red);
+    // axis limits, equal aspect inside the square figure, box centred
+    const double x0 = xmin - 1.0, x1 = xmax + 1.0, y0 = ymin - 1.0, y1 = ymax + 1.0;
+    const double W = x1 - x0, H = y1 - y0;
+    const double dres = (double)res;
+    const double sx = dres / W, sy = dres / H;
+    const double s = sx < sy ? sx : sy;
+    const double offx = (dres - W * s) / 2.0, offy = (dres - H * s) / 2.0;
+
+    const int K = A.K, half = K / 2;
+    const int cell_dy = t / K - half, cell_dx = t % K - half;
+    const uint32_t alpha = t < K * K ? A.stamp[t] : 0u;
+    const uint32_t den = ((alpha + 255u) << 8) - alpha * 255u;
+    const float inv_den = 1.0f / (float)den;
+    const uint32_t marker = (uint32_t)A.marker;
+
+    for (int64_t c0 = 0; c0 < n; c0 += RENDER_CHUNK) {
+        const int m = (int)(n - c0 < RENDER_CHUNK ? n - c0 : RENDER_CHUNK);
+        __syncthreads();
+        for (int i = t; i < m; i += FX_BLOCK) {
+            double X, Y;
+            plane(c0 + i, X, Y);
+            const double px = offx + (X - x0) * s;
+            const double py = offy + (Y - y0) * s;
+            const int col = (int)floor(px + 0.5);
+            const int row = (int)floor((dres - py) + 0.5);
+            // stored with a bias so that positions a little outside the canvas stay representable
+            s_snap[i] = ((uint32_t)(row + 1024) << 16) | (uint32_t)(col + 1024);
+        }
+        __syncthreads();
+        if (t < FX_WAVE && alpha != 0u) {
+            for (int i = 0; i < m; i++) {
+                const uint32_t rc = s_snap[i];
+                const int row = (int)(rc >> 16) - 1024 + cell_dy;
+                const int col = (int)(rc & 0xFFFFu) - 1024 + cell_dx;
+                if (row >= 0 && row < res && col >= 0 && col < res) {
+                    const int at = row * res + col;
+                    const uint32_t p = canvas[at];
+                    canvas[at] = (uint8_t)(alpha == 255u ? marker : agg_blend(p, marker, alpha, den, inv_den));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    uint8_t *out = A.out + bv * (int64_t)npx;
+    if ((npx & 15) == 0 && ((uintptr_t)out & 15) == 0) {
+        for (int i = t * 16; i < npx; i += FX_BLOCK * 16)
+            *reinterpret_cast<uint4 *>(out + i) = *reinterpret_cast<const uint4 *>(canvas + i);
+    } else {
+        for (int i = t; i < npx; i += FX_BLOCK)
+            out[i] = canvas[i];
+    }
+}
+
+// Per cloud: minimum and maximum of every coordinate and the mean as
+// np.mean(axis=0) forms it (rows added one after the other in float64, then
+// one division).  One wave per cloud.
+__global__ __launch_bounds__(FX_BLOCK) void cloud_bounds_kernel(const float *pts_all, const int64_t *offsets, int64_t B,
+                                                              double *bounds)
+{
+    const int lane = fx_lane();
+    const int64_t b = (int64_t)blockIdx.x * FX_WAVES_PER_BLOCK + fx_wave();
+    if (b >= B)
+        return;
+    const int64_t lo = offsets[b], n = offsets[b + 1] - lo;
+    const float *pts = pts_all + lo * 3;
+    const float inf = __builtin_inff();
+    float mn[3] = {inf, inf, inf}, mx[3] = {-inf, -inf, -inf};
+    for (int64_t i = lane; i < n; i += FX_WAVE) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float v = pts[i * 3 + c];
+            mn[c] = fminf(mn[c], v);
+            mx[c] = fmaxf(mx[c], v);
+        }
+    }
+    double *o = bounds + b * 9;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float lo_c = -fx_wave_max_f32_dpp(-mn[c]), hi_c = fx_wave_max_f32_dpp(mx[c]);
+        if (lane == 0) {
+            o[c] = (double)lo_c;
+            o[3 + c] = (double)hi_c;
+        }
+    }
+    if (lane < 3) {
+        double sum = 0.0;
+        int64_t i = 0;
+        for (; i + 8 <= n; i += 8) {
+            double w[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                w[j] = (double)pts[(i + j) * 3 + lane];
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                sum += w[j];
+        }
+        for (; i < n; i++)
+            sum += (double)pts[i * 3 + lane];
+        o[6 + lane] = sum / (double)n;
+    }
+}
+
+}  // namespace
+
+extern "C" int fx_cloud_bounds_f32(const float *d_pts, const int64_t *d_offsets, int64_t B, double *d_bounds, void *stream)
+{
+    FX_REQUIRE(B >= 0, "fx_cloud_bounds_f32: B = %lld", (long long)B);
+    if (B == 0)
+        return FX_OK;
+    FX_REQUIRE(d_pts && d_offsets && d_bounds, "fx_cloud_bounds_f32: NULL argument");
+    hipLaunchKernelGGL(cloud_bounds_kernel, dim3((unsigned)((B + FX_WAVES_PER_BLOCK - 1) / FX_WAVES_PER_BLOCK)), dim3(FX_BLOCK), 0,
+                       (hipStream_t)stream, d_pts, d_offsets, B, d_bounds);
+    FX_HIP_CHECK(hipGetLastError());
+    return FX_OK;
+}
+
+extern "C" int fx_render_views_u8(const float *d_pts, const int64_t *d_offsets, int64_t B, int V, const double *d_cam,
+                                  const double *d_scale, int resolution, const uint8_t *stamp, int K, int marker_value,
+                                  uint8_t *d_out, void *stream)
+{
+    FX_REQUIRE(B >= 0 && V >= 1, "fx_render_views_u8: %lld clouds x %d views", (long long)B, V);
+    if (B == 0)
+        return FX_OK;
+    FX_REQUIRE(d_pts && d_offsets && d_cam && d_scale && stamp && d_out, "fx_render_views_u8: NULL argument");
+    FX_REQUIRE(resolution >= 8 && resolution <= RENDER_MAX_RES, "fx_render_views_u8: resolution %d outside 8..%d", resolution,
+               RENDER_MAX_RES);
+    FX_REQUIRE(K >= 1 && K <= RENDER_MAX_K && (K & 1), "fx_render_views_u8: stamp side %d (odd, at most %d)", K, RENDER_MAX_K);
+    FX_REQUIRE(marker_value == 0 || marker_value == 255, "fx_render_views_u8: marker value %d (0 or 255)", marker_value);
+    FX_REQUIRE(B * V <= 0x7fffffffLL, "fx_render_views_u8: too many views for one launch");
+    RenderArgs A;
+    A.pts = d_pts;
+    A.offsets = d_offsets;
+    A.B = B;
+    A.V = V;
+    A.cam = d_cam;
+    A.scale = d_scale;
+    A.res = resolution;
+    A.K = K;
+    A.marker = marker_value;
+    for (int i = 0; i < RENDER_MAX_K * RENDER_MAX_K; i++)
+        A.stamp[i] = i < K * K ? stamp[i] : 0;
+    A.out = d_out;
+    const size_t lds = ((size_t)resolution * resolution + 15) & ~(size_t)15;
+    if (lds > 48 * 1024)
+        FX_HIP_CHECK(hipFuncSetAttribute((const void *)render_views_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    FxProfileScope prof((hipStream_t)stream);
+    hipLaunchKernelGGL(render_views_kernel, dim3((unsigned)(B * V)), dim3(FX_BLOCK), lds, (hipStream_t)stream, A);
+    FX_HIP_CHECK(hipGetLastError());
+    return FX_OK;
+}

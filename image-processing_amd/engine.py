@@ -317,6 +317,55 @@ def binarize_ge(x: torch.Tensor, thr: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def cloud_bounds(points: torch.Tensor, offsets: torch.Tensor) -> torch.Tensor:
+    """float64 [B, 9] = min xyz, max xyz, mean xyz of B clouds stored back to
+    back (float32 [total, 3], int64 offsets [B + 1], both on the device), as
+    the reference's bbox_and_center (src/preprocessing/render_views.py:77-87)."""
+    _require_cuda(points, "points")
+    _require_cuda(offsets, "offsets")
+    if points.dim() != 2 or points.shape[1] != 3 or points.dtype != torch.float32 or not points.is_contiguous():
+        raise ValueError("points must be contiguous float32 [total, 3]")
+    if offsets.dtype != torch.int64 or offsets.dim() != 1 or offsets.numel() < 1 or not offsets.is_contiguous():
+        raise ValueError("offsets must be contiguous int64 [B + 1]")
+    stream = _enter(points.device)
+    B = offsets.numel() - 1
+    out = torch.empty((B, 9), dtype=torch.float64, device=points.device)
+    if B:
+        _lib.call("fx_cloud_bounds_f32", points.data_ptr(), offsets.data_ptr(), B, out.data_ptr(), stream)
+    return out
+
+
+def render_views(points: torch.Tensor, offsets: torch.Tensor, cam: torch.Tensor, scale: torch.Tensor, resolution: int,
+                 stamp, marker_value: int = 0) -> torch.Tensor:
+    """uint8 [B, V, res, res] views of B clouds (layout as cloud_bounds) from
+    the camera table cam (float64 [B, V, 9]: right, true_up, look-at) and the
+    per-cloud scale (float64 [B]); `stamp` is the K x K uint8 coverage stamp of
+    the marker (host array).  Reference: render_fallback_matplotlib,
+    src/preprocessing/render_views.py:294-366."""
+    import numpy as np
+    for name, t in (("points", points), ("offsets", offsets), ("cam", cam), ("scale", scale)):
+        _require_cuda(t, name)
+    if points.dim() != 2 or points.shape[1] != 3 or points.dtype != torch.float32 or not points.is_contiguous():
+        raise ValueError("points must be contiguous float32 [total, 3]")
+    B = offsets.numel() - 1
+    if offsets.dtype != torch.int64 or not offsets.is_contiguous():
+        raise ValueError("offsets must be contiguous int64 [B + 1]")
+    if cam.dtype != torch.float64 or cam.dim() != 3 or cam.shape[0] != B or cam.shape[2] != 9 or not cam.is_contiguous():
+        raise ValueError("cam must be contiguous float64 [B, V, 9]")
+    if scale.dtype != torch.float64 or scale.shape != (B,) or not scale.is_contiguous():
+        raise ValueError("scale must be contiguous float64 [B]")
+    st = np.ascontiguousarray(stamp, dtype=np.uint8)
+    if st.ndim != 2 or st.shape[0] != st.shape[1]:
+        raise ValueError("stamp must be a square uint8 array")
+    V, res = int(cam.shape[1]), int(resolution)
+    stream = _enter(points.device)
+    out = torch.empty((B, V, res, res), dtype=torch.uint8, device=points.device)
+    if B and V:
+        _lib.call("fx_render_views_u8", points.data_ptr(), offsets.data_ptr(), B, V, cam.data_ptr(), scale.data_ptr(), res,
+                  st.ctypes.data, int(st.shape[0]), int(marker_value), out.data_ptr(), stream)
+    return out
+
+
 def synth_shapes(B: int, H: int, W: int, seed: int = 42, first_index: int = 0, device="cuda",
                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """B synthetic {0,255} shape images generated on the device."""

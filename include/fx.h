@@ -303,6 +303,33 @@ int fx_binarize_ge_f64(const double *d_x, int64_t rows, int cols,
                        void *stream);
 
 /*
+ * Renderer of the views the Hu path reads: render_fallback_matplotlib,
+ * src/preprocessing/render_views.py:294-366 (the reference's renderer when
+ * neither Open3D nor pyrender is installed), for B clouds x V camera poses.
+ * d_pts: float32 [total, 3] with d_offsets[B + 1] (device).  d_cam: float64
+ * [B, V, 9] = right, true_up (:312-320) and the look-at point of every pose;
+ * d_scale[B] = (resolution * 0.35) / bbox diagonal (:329-333).  The kernel
+ * projects (:323-335), applies the axis limits and equal-aspect box of
+ * :353-355 on a resolution x resolution figure, snaps every marker to a pixel
+ * as matplotlib's Agg backend does and blends the K x K coverage stamp of the
+ * marker (host array, row-major, what Agg rasterises for the given point
+ * size) in point order with Agg's integer blend onto a white canvas.
+ * marker_value: 0 (bg_color "white") or 255 ("black": white markers; the
+ * figure stays white because the axes patch is switched off, :344-349).
+ * d_out: uint8 [B, V, resolution, resolution], the R = G = B channel of the
+ * reference's image.  resolution <= 384.
+ *
+ * fx_cloud_bounds_f32: per cloud min xyz, max xyz, mean xyz (float64 [B, 9])
+ * as bbox_and_center :77-87 computes them from the float32 file values.
+ */
+int fx_cloud_bounds_f32(const float *d_pts, const int64_t *d_offsets, int64_t B,
+                        double *d_bounds, void *stream);
+int fx_render_views_u8(const float *d_pts, const int64_t *d_offsets, int64_t B,
+                       int V, const double *d_cam, const double *d_scale,
+                       int resolution, const uint8_t *stamp, int K,
+                       int marker_value, uint8_t *d_out, void *stream);
+
+/*
  * Synthetic inputs for benchmarks and parity tests (no reference counterpart:
  * the reference reads rendered PNG views and sampled .npy clouds from disk).
  * Image `first_index + b` / set `first_index + b` depends only on (seed, that

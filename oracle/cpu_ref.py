@@ -464,6 +464,125 @@ def build_c_oracle(force: bool = False) -> Path:
     return so
 
 
+# ---- view renderer without Open3D / pyrender (reference src/preprocessing/render_views.py) ----
+
+def bbox_and_center(points: np.ndarray):
+    """bbox_and_center :77-87: min, max, mean, diagonal."""
+    mins = points.min(axis=0)
+    maxs = points.max(axis=0)
+    return mins, maxs, points.mean(axis=0), float(np.linalg.norm(maxs - mins))
+
+
+def compute_camera_poses(n_views: int, bbox_min, bbox_max, centroid, radius_factor: float = 2.0, seed: int = 42,
+                         elevation_levels=None):
+    """compute_camera_poses :93-164: rings of cameras at the given elevations
+    (default -30, 0, 30 degrees), azimuths evenly spaced per ring plus a jitter
+    of +-1e-6 degrees from RandomState(seed), radius = radius_factor * bbox
+    diagonal, all looking at the centroid with z up."""
+    import math
+    if elevation_levels is None:
+        elevation_levels = [-30.0, 0.0, 30.0]
+    n_elev = len(elevation_levels)
+    per_level = max(1, n_views // n_elev)
+    counts = [per_level] * n_elev
+    for i in range(n_views - per_level * n_elev):
+        counts[i] += 1
+    diag = float(np.linalg.norm(bbox_max - bbox_min))
+    radius = diag * radius_factor if diag > 1e-9 else radius_factor
+    rng = np.random.RandomState(seed)
+    poses = []
+    for elev, cnt in zip(elevation_levels, counts):
+        for k in range(cnt):
+            az = float((360.0 * k) / max(1, cnt)) + float(rng.uniform(-1e-6, 1e-6))
+            el_rad, az_rad = math.radians(elev), math.radians(az)
+            offset = np.array([radius * math.cos(el_rad) * math.cos(az_rad),
+                               radius * math.cos(el_rad) * math.sin(az_rad),
+                               radius * math.sin(el_rad)], dtype=np.float64)
+            position = offset + centroid
+            up = np.array([0.0, 0.0, 1.0])
+            fwd = centroid - position
+            if np.linalg.norm(fwd) < 1e-9:
+                fwd = np.array([0.0, 0.0, 1.0])
+            fwd = fwd / np.linalg.norm(fwd)
+            if abs(np.dot(fwd, up)) > 0.999:
+                up = np.array([0.0, 1.0, 0.0])
+            poses.append({"position": position, "lookat": centroid.copy(), "up": up, "elevation": elev, "azimuth": az})
+    if len(poses) > n_views:
+        poses = poses[:n_views]
+    while len(poses) < n_views:
+        poses.append(poses[len(poses) % len(poses)])
+    return poses
+
+
+def camera_plane(pose):
+    """Camera basis of render_fallback_matplotlib :306-320: right, true_up."""
+    eye, center = pose["position"], pose["lookat"]
+    up = pose["up"].astype(np.float64)
+    forward = center - eye
+    if np.linalg.norm(forward) < 1e-12:
+        forward = np.array([0.0, 0.0, 1.0])
+    forward = forward / np.linalg.norm(forward)
+    right = np.cross(forward, up)
+    if np.linalg.norm(right) < 1e-9:
+        right = np.cross(forward, np.array([0.0, 1.0, 0.0]))
+    right = right / (np.linalg.norm(right) + 1e-12)
+    true_up = np.cross(right, forward)
+    true_up = true_up / (np.linalg.norm(true_up) + 1e-12)
+    return right, true_up
+
+
+def agg_blend(p: int, c: int, alpha: int) -> int:
+    """One channel of Agg's fixed_blender_rgba_plain on an opaque pixel
+    (matplotlib src/agg_workaround.h): value p, source c, alpha 0..255."""
+    if alpha == 0:
+        return p
+    if alpha == 255:
+        return c
+    r = p * 255
+    a = ((alpha + 255) << 8) - alpha * 255
+    return (((c << 8) - r) * alpha + (r << 8)) // a
+
+
+def render_view(points: np.ndarray, pose, resolution: int, stamp, bg_color: str = "white") -> np.ndarray:
+    """render_fallback_matplotlib :294-366 as matplotlib's Agg backend executes
+    it, uint8 [res, res] (R = G = B): projection and scale :322-335; axis limits
+    min-1 .. max+1 with equal aspect on the square, decoration-free figure
+    (:337-355; the data box is scaled by min(res/W, res/H) and centred); every
+    marker snapped to the pixel (floor(px+0.5), floor(res-py+0.5)); the marker's
+    coverage stamp blended in point order onto the white figure (the axes patch
+    is off, so the background stays white for either bg_color)."""
+    res = int(resolution)
+    right, true_up = camera_plane(pose)
+    rel = points - pose["lookat"]
+    x, y = rel.dot(right), rel.dot(true_up)
+    diag = float(np.linalg.norm(points.max(axis=0) - points.min(axis=0)))
+    if diag < 1e-9:
+        diag = 1.0
+    scale = (res * 0.35) / diag
+    xs, ys = x * scale, y * scale
+    x0, x1 = np.min(xs) - 1, np.max(xs) + 1
+    y0, y1 = np.min(ys) - 1, np.max(ys) + 1
+    W, H = x1 - x0, y1 - y0
+    s = min(res / W, res / H)
+    offx, offy = (res - W * s) / 2.0, (res - H * s) / 2.0
+    px = offx + (xs - x0) * s
+    py = offy + (ys - y0) * s
+    cols = np.floor(px + 0.5).astype(np.int64)
+    rows = np.floor((res - py) + 0.5).astype(np.int64)
+    stamp = np.asarray(stamp, dtype=np.int64)
+    K = stamp.shape[0]
+    half = K // 2
+    marker = 0 if bg_color == "white" else 255
+    img = np.full((res, res), 255, dtype=np.int64)
+    cells = [(j - half, i - half, int(stamp[j, i])) for j in range(K) for i in range(K) if stamp[j, i]]
+    for r0, c0 in zip(rows.tolist(), cols.tolist()):
+        for dj, di, a in cells:
+            r, c = r0 + dj, c0 + di
+            if 0 <= r < res and 0 <= c < res:
+                img[r, c] = agg_blend(int(img[r, c]), marker, a)
+    return img.astype(np.uint8)
+
+
 # ---- feature binarisation thresholds (reference src/models/train_bernoulli_nb.py:307-385) ----
 
 def otsu_threshold_1d(values: np.ndarray) -> float:

@@ -234,6 +234,110 @@ def make_thresholds(ref: Path) -> None:
     print(f"thresholds_golden.npz: {k} cases")
 
 
+def measure_stamps() -> dict:
+    """Coverage stamps of matplotlib's round scatter marker per marker area:
+    one marker drawn on figures of four gray levels; the alpha of every cell is
+    the only value consistent with Agg's blend on all four."""
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+    from io import BytesIO
+    from PIL import Image
+
+    def blend(p, c, a):
+        if a == 0:
+            return p
+        r = p * 255
+        return ((((c << 8) - r) * a + (r << 8)) & 0xFFFFFFFF) // (((a + 255) << 8) - a * 255)
+
+    def draw(s, gray, res=64):
+        fig = plt.figure(figsize=(res / 100.0, res / 100.0), dpi=100, facecolor=(gray / 255.0,) * 3)
+        ax = fig.add_subplot(111)
+        ax.scatter([32.2], [31.7], s=s, color=(0, 0, 0), marker="o", linewidths=0, alpha=1.0)
+        ax.axis("off")
+        ax.set_frame_on(False)
+        ax.set_xlim(0, res)
+        ax.set_ylim(0, res)
+        ax.set_aspect("equal", adjustable="box")
+        fig.subplots_adjust(0, 0, 1, 1)
+        buf = BytesIO()
+        fig.canvas.print_png(buf)
+        buf.seek(0)
+        img = np.asarray(Image.open(buf).convert("RGB"))[:, :, 0].astype(int)
+        plt.close(fig)
+        return img
+
+    out = {}
+    R = 9
+    for s in (0.5, 1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 8.0, 10.0, 12.0, 16.0, 20.0, 25.0):
+        cands = None
+        for g in (255, 200, 128, 64):
+            win = draw(s, g)[32 - R:32 + R + 1, 32 - R:32 + R + 1]
+            sets = [[{a for a in range(256) if blend(g, 0, a) == win[j, i]} for i in range(2 * R + 1)] for j in range(2 * R + 1)]
+            cands = sets if cands is None else [[cands[j][i] & sets[j][i] for i in range(2 * R + 1)] for j in range(2 * R + 1)]
+        assert all(len(c) == 1 for row in cands for c in row), f"marker area {s}: coverage not unique"
+        al = np.array([[min(c) for c in row] for row in cands])
+        ys, xs = np.nonzero(al)
+        k = int(max(np.abs(ys - R).max(), np.abs(xs - R).max()))
+        out[s] = al[R - k:R + k + 1, R - k:R + k + 1].astype(np.uint8)
+    return out
+
+
+def make_render(ref: Path) -> None:
+    """Views drawn by the reference's own render_fallback_matplotlib
+    (src/preprocessing/render_views.py) for seeded clouds, with the poses of its
+    compute_camera_poses, plus the marker stamps measured from matplotlib; also
+    rewrites image-processing_amd/marker_stamps.py from the same measurement."""
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, str(ref / "src" / "preprocessing"))
+    mod = importlib.import_module("render_views")
+    stamps = measure_stamps()
+    lines = ['"""Coverage stamps of matplotlib\'s round scatter marker (marker="o", linewidths=0)',
+             "at dpi 100, per marker area `s` in points^2: what the Agg backend rasterises",
+             "once per draw call and blends at every snapped point position.  Measured from",
+             "matplotlib 3.10 (tests/golden/make_golden.py::make_render writes this table);",
+             'rows top to bottom."""', "", "STAMPS = {"]
+    for k in sorted(stamps):
+        lines.append(f"    {float(k)!r}: (")
+        for r in stamps[k].tolist():
+            lines.append("        (" + ", ".join(f"{v:3d}" for v in r) + ("," if len(r) == 1 else "") + "),")
+        lines.append("    ),")
+    lines.append("}\n")
+    (HERE.parent.parent / "image-processing_amd" / "marker_stamps.py").write_text("\n".join(lines))
+    rng = np.random.default_rng(20251113)
+    out = {f"stamp_{k!r}": v for k, v in stamps.items()}
+    out["stamp_sizes"] = np.array(sorted(stamps))
+    specs = [(1024, 224, 2.0, "white", 12, (0, 4, 7, 11)), (1024, 224, 2.0, "white", 12, (1, 5, 9)),
+             (300, 224, 1.0, "white", 12, (2, 6)), (2048, 128, 4.0, "white", 6, (0, 3)),
+             (1024, 224, 8.0, "white", 12, (3, 10)), (5000, 300, 2.0, "white", 12, (0, 8)),
+             (1024, 224, 2.0, "black", 12, (0,)), (64, 96, 16.0, "white", 5, (0, 4)), (1, 64, 2.0, "white", 3, (0,))]
+    k = 0
+    for ci, (n, res, ps, bg, views, chosen) in enumerate(specs):
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        pts = (rng.normal(size=(n, 3)) * np.exp(rng.uniform(-1.5, 0.5, size=3))) @ q.T + rng.normal(size=3)
+        if ci == 1:                       # a tree-like cloud: trunk + crown, many overlapping markers
+            trunk = np.c_[rng.normal(0, 0.02, 300), rng.normal(0, 0.02, 300), rng.uniform(-1, 0, 300)]
+            crown = rng.normal(size=(724, 3)) * [0.35, 0.3, 0.45] + [0, 0, 0.4]
+            pts = np.concatenate([trunk, crown])
+        pts = pts.astype(np.float32)
+        p64 = pts.astype(np.float64)
+        mins, maxs, cen, _ = mod.bbox_and_center(p64)
+        poses = mod.compute_camera_poses(views, mins, maxs, cen, radius_factor=2.0, seed=42)
+        out[f"pts_{ci}"] = pts
+        out[f"poses_{ci}"] = np.stack([np.concatenate([q_["position"], q_["lookat"], q_["up"]]) for q_ in poses])
+        for v in chosen:
+            img = mod.render_fallback_matplotlib(p64, poses[v], res, ps, bg, False)
+            a = np.asarray(img.convert("RGB"))
+            assert (a[:, :, 0] == a[:, :, 1]).all() and (a[:, :, 0] == a[:, :, 2]).all()
+            out[f"img_{k}"] = a[:, :, 0].copy()
+            out[f"meta_{k}"] = np.array([str(ci), str(v), str(res), repr(ps), bg, str(views)])
+            k += 1
+    out["n_cases"] = np.array(k)
+    out["n_clouds"] = np.array(len(specs))
+    np.savez_compressed(HERE / "render_golden.npz", **out)
+    print(f"render_golden.npz: {k} views of {len(specs)} clouds")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default=os.environ.get("FX_REFERENCE", "/root/reference"))
@@ -243,3 +347,4 @@ if __name__ == "__main__":
     make_preprocess(Path(a.reference))
     make_fps(Path(a.reference))
     make_thresholds(Path(a.reference))
+    make_render(Path(a.reference))

@@ -1,0 +1,112 @@
+"""View renderer on the device against views drawn by the reference's own
+render_fallback_matplotlib (golden: matplotlib's Agg output) and against the
+oracle's restatement on seeded clouds: identical pixels."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+from test_oracle import render_cases
+
+pytestmark = pytest.mark.gpu
+
+
+def test_golden_views_of_the_reference(gpu):
+    rv = pkg("render_views")
+    done = {}
+    for k, pts, poses, v, res, ps, bg, views, img, stamps in render_cases():
+        key = (pts.tobytes(), res, ps, bg, views)
+        if key not in done:
+            done[key] = rv.render_views_batch([pts], views, res, ps, bg).cpu().numpy()[0]
+        got = done[key][v]
+        diff = int((got != img).sum())
+        assert diff == 0, f"case {k}: {diff} pixels differ ({len(pts)} points, {res} px, size {ps}, {bg}, view {v})"
+        # the single-view function with the reference's pose dictionary
+        pose = {"position": poses[v, 0:3], "lookat": poses[v, 3:6], "up": poses[v, 6:9]}
+        one = rv.render_fallback_matplotlib(pts.astype(np.float64), pose, res, ps, bg, False)
+        assert one.mode == ("RGB" if bg == "white" else "RGBA") and one.size == (res, res)
+        np.testing.assert_array_equal(np.asarray(one.convert("RGB"))[:, :, 0], img)
+
+
+def test_batches_against_oracle(gpu, oracle):
+    """Ragged batches, clouds larger than one LDS chunk of snapped positions,
+    degenerate clouds (a single point, all points equal, a line)."""
+    rv = pkg("render_views")
+    rng = np.random.default_rng(77)
+    clouds = []
+    for n in (1, 2, 50, 1024, 1024, 3000, 4097):
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        clouds.append(((rng.normal(size=(n, 3)) * np.exp(rng.uniform(-2, 1, size=3))) @ q.T + rng.normal(size=3) * 3).astype(np.float32))
+    clouds.append(np.tile(np.array([[0.5, -1.0, 2.0]], dtype=np.float32), (30, 1)))
+    clouds.append(np.c_[np.linspace(-1, 1, 200), np.zeros(200), np.zeros(200)].astype(np.float32))
+    for res, ps, views in ((224, 2.0, 12), (96, 5.0, 4), (384, 1.0, 3)):
+        got = rv.render_views_batch(clouds, views, res, ps).cpu().numpy()
+        assert got.shape == (len(clouds), views, res, res)
+        stamp = rv.marker_stamp(ps)
+        for b, c in enumerate(clouds):
+            p64 = c.astype(np.float64)
+            mins, maxs, cen, _ = oracle.bbox_and_center(p64)
+            poses = oracle.compute_camera_poses(views, mins, maxs, cen, 2.0, 42)
+            for v in (0, views - 1):
+                want = oracle.render_view(p64, poses[v], res, stamp)
+                diff = int((got[b, v] != want).sum())
+                assert diff == 0, f"cloud {b} ({len(c)} points) view {v} at {res} px, size {ps}: {diff} pixels differ"
+
+
+def test_bounds_poses_and_errors(gpu, oracle):
+    rv, eng = pkg("render_views"), pkg("engine")
+    rng = np.random.default_rng(5)
+    clouds = [rng.normal(size=(n, 3)).astype(np.float32) * 10 for n in (1, 7, 1000, 20000)]
+    pts, off = rv.pack_clouds(clouds, gpu)
+    b = eng.cloud_bounds(pts, off).cpu().numpy()
+    for k, c in enumerate(clouds):
+        mins, maxs, cen, _ = oracle.bbox_and_center(c.astype(np.float64))
+        np.testing.assert_array_equal(b[k], np.concatenate([mins, maxs, cen]))
+    mins, maxs, cen, _ = rv.bbox_and_center(clouds[2].astype(np.float64))
+    for views, levels in ((12, None), (5, None), (2, None), (7, [10.0, 89.99])):
+        mine = rv.compute_camera_poses(views, mins, maxs, cen, 2.0, 42, levels)
+        ref = oracle.compute_camera_poses(views, mins, maxs, cen, 2.0, 42, levels)
+        assert len(mine) == len(ref) == views
+        for a, r in zip(mine, ref):
+            for key in ("position", "lookat", "up"):
+                np.testing.assert_array_equal(a[key], r[key])
+    with pytest.raises(ValueError, match="no marker stamp"):
+        rv.render_views_batch(clouds[:1], 3, 64, 2.5)
+    with pytest.raises(ValueError, match="empty point cloud"):
+        rv.render_views_batch([np.zeros((0, 3), np.float32)], 3, 64)
+    with pytest.raises(pkg("_lib").FxError):
+        rv.render_views_batch(clouds[:1], 3, 1000)
+
+
+def test_directory_run_and_views_feed_the_hu_path(gpu, tmp_path, oracle):
+    """The script writes what the reference's writes (views, manifest, config),
+    and the views it keeps on the device give the Hu features of the PNGs."""
+    import pandas as pd
+    from PIL import Image
+    rv, hu = pkg("render_views"), pkg("extract_2d_hu")
+    rng = np.random.default_rng(9)
+    sampled = tmp_path / "sampled"
+    sampled.mkdir()
+    clouds = {}
+    for name in ("Buche_1", "Eiche_2", "Kiefer_3"):
+        c = (rng.normal(size=(1024, 3)) * [0.3, 0.25, 0.6]).astype(np.float32)
+        np.save(sampled / f"{name}.npy", c)
+        clouds[name] = c
+    np.save(sampled / "broken.npy", np.zeros((5, 2), np.float32))
+    out = tmp_path / "views"
+    rc = rv.main(["--sampled_dir", str(sampled), "--out_dir", str(out), "--views", "6", "--resolution", "128",
+                  "--reports_dir", str(tmp_path / "reports"), "--n_preview", "2"])
+    assert rc == 0
+    man = pd.read_csv(out / "manifest_views.csv")
+    assert list(man.columns) == ["id", "sample_path", "views_dir", "n_views", "note", "rendered_timestamp"]
+    assert sorted(man["id"]) == ["Buche_1", "Eiche_2", "Kiefer_3", "broken"]
+    assert man.set_index("id").loc["broken", "note"].startswith("failed: invalid shape")
+    assert (out / "render_config.yaml").exists() and (tmp_path / "reports" / "read_errors.log").exists()
+    assert len(list((tmp_path / "reports" / "sample_images").glob("*_preview.png"))) == 2
+    batch = rv.render_views_batch([clouds["Eiche_2"]], 6, 128).cpu().numpy()[0]
+    for v in range(6):
+        png = np.asarray(Image.open(out / "Eiche_2" / f"view_{v + 1:02d}.png").convert("L"))
+        np.testing.assert_array_equal(png, batch[v])
+    mins, maxs, cen, _ = oracle.bbox_and_center(clouds["Eiche_2"].astype(np.float64))
+    pose = oracle.compute_camera_poses(6, mins, maxs, cen)[3]
+    np.testing.assert_array_equal(batch[3], oracle.render_view(clouds["Eiche_2"].astype(np.float64), pose, 128, rv.marker_stamp(2.0)))

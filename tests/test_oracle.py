@@ -1,5 +1,6 @@
 """The CPU oracle against the reference's own outputs and artefacts (no GPU)."""
 import csv
+import importlib
 
 import numpy as np
 import pytest
@@ -192,3 +193,32 @@ def test_thresholds_restatement_equals_reference_outputs(oracle):
         np.testing.assert_array_equal(oracle.apply_thresholds(table, thr), bits)
         n += 1
     assert n == 80
+
+
+# ------------------------------------------------------------ view renderer
+def render_cases():
+    g = np.load(GOLDEN / "render_golden.npz")
+    stamps = {float(s): g[f"stamp_{float(s)!r}"] for s in g["stamp_sizes"]}
+    for k in range(int(g["n_cases"])):
+        ci, v, res, ps, bg, views = (str(x) for x in g[f"meta_{k}"])
+        yield k, g[f"pts_{ci}"], g[f"poses_{ci}"], int(v), int(res), float(ps), bg, int(views), g[f"img_{k}"], stamps
+
+
+def test_render_restatement_equals_reference_outputs(oracle):
+    """render_golden.npz holds views drawn by the reference's own
+    render_fallback_matplotlib (matplotlib Agg) and the poses of its
+    compute_camera_poses: the restatement reproduces both bit for bit."""
+    pkg_stamps = importlib.import_module("image-processing_amd.marker_stamps").STAMPS
+    n = 0
+    for k, pts, poses, v, res, ps, bg, views, img, stamps in render_cases():
+        p64 = pts.astype(np.float64)
+        mins, maxs, cen, _ = oracle.bbox_and_center(p64)
+        mine = oracle.compute_camera_poses(views, mins, maxs, cen, 2.0, 42)
+        got = np.stack([np.concatenate([q["position"], q["lookat"], q["up"]]) for q in mine])
+        np.testing.assert_array_equal(got, poses, err_msg=f"case {k}: poses")
+        np.testing.assert_array_equal(np.array(pkg_stamps[ps], dtype=np.uint8), stamps[ps])
+        out = oracle.render_view(p64, mine[v], res, stamps[ps], bg)
+        diff = int((out != img).sum())
+        assert diff == 0, f"case {k}: {diff} pixels differ ({len(pts)} points, {res} px, size {ps}, {bg})"
+        n += 1
+    assert n == 19

@@ -126,6 +126,17 @@ if __name__ == "__main__":
             for _ in range(5): eng.binarize_ge(x, thr)
             torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5 * 1e3
             print(f"binarize {rows}x{cols}: {dt:.3f} ms  {rows*cols*9/dt/1e6:.0f} GB/s", flush=True)
+    elif what == "render":
+        rv = importlib.import_module("image-processing_amd.render_views")
+        for B, N, V, res in ((2000, 1024, 12, 224), (557, 1024, 12, 224), (200, 8192, 12, 224)):
+            pts = eng.synth_points(B, N, seed=42, device=dev).reshape(B * N, 3).contiguous()
+            off = torch.arange(B + 1, dtype=torch.int64, device=dev) * N
+            rv.render_views_device(pts, off, V, res); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3): rv.render_views_device(pts, off, V, res)
+            torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3 * 1e3
+            eng.profile(True); rv.render_views_device(pts, off, V, res); k = eng.profile_last_ms(); eng.profile(False)
+            print(f"render B={B} N={N} V={V} {res}px: {dt:.2f} ms per call ({B*V/dt:.0f} k views/s), kernel {k:.2f} ms", flush=True)
     elif what == "sil1":
         ms, gbps = time_sil(20000, 224, 224, 224, reps=3)
         print(f"sil B=20000 224x224->224: {ms:.3f} ms  {gbps:.0f} GB/s", flush=True)
