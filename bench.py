@@ -49,6 +49,9 @@ WORKLOADS = {
     "f1": dict(kind="sil+hu", per_gpu=20_000, H=224, W=224, bytes_per_unit=224 * 224, scaling="weak",
                desc="20k gray 224x224 views per GPU; silhouette preprocessing (blur, Otsu, morphology, crop, "
                     "resize, component filter) + Hu"),
+    "p1": dict(kind="views+hu", per_gpu=2_000, N=1024, bytes_per_unit=1024 * 3 * 4, scaling="weak",
+               desc="2k sampled clouds of 1024x3 f32 per GPU; 12 rendered 224x224 views each (the reference's matplotlib "
+                    "renderer) -> preprocessing -> Hu -> per-sample mean/std, all in HBM"),
 }
 
 
@@ -85,10 +88,13 @@ def cpu_baseline(kind: str, sample, cores: int) -> dict:
             done = pool.map(cb.run, jobs)
             wall = time.perf_counter() - t0
     units = sum(d[0] for d in done)
-    return {"value": units / wall, "unit": "images/s" if kind != "pca" else "sets/s", "cores": len(jobs), "kind": "port",
+    return {"value": units / wall, "unit": {"pca": "sets/s", "views+hu": "clouds/s"}.get(kind, "images/s"), "cores": len(jobs),
+            "kind": "port",
             "sample": f"{units} units of the benchmark's own synthetic data, {wall:.1f} s wall on {len(jobs)} worker processes "
                       f"(C restatement of cv2.moments/HuMoments + NumPy cov/eigh/histogram per unit"
-                      + ("; PIL + scipy.ndimage silhouette as in the reference" if kind == "sil+hu" else "") + ")"}
+                      + ("; PIL + scipy.ndimage silhouette as in the reference" if kind == "sil+hu" else "")
+                      + ("; NumPy restatement of the matplotlib renderer, 12 views per cloud, PIL + scipy.ndimage preprocessing"
+                         if kind == "views+hu" else "") + ")"}
 
 
 def main():
@@ -117,7 +123,15 @@ def main():
     kind = wl["kind"]
 
     # ---------------- resident synthetic batch ------------------------------
-    if kind == "pca":
+    if kind == "views+hu":
+        hu2d = importlib.import_module("image-processing_amd.extract_2d_hu")
+        units = args.units or wl["per_gpu"]
+        total = units * world
+        lo = rank * units
+        data = eng.synth_points(units, wl["N"], seed=42, first_index=lo, device=dev)
+        cloud_off = torch.arange(units + 1, dtype=torch.int64, device=dev) * wl["N"]
+        flat = data.reshape(units * wl["N"], 3)
+    elif kind == "pca":
         total = args.units * world if args.units else wl["total"]
         lo, hi = fxdist.shard_range(total, rank, world)
         units = hi - lo
@@ -147,6 +161,9 @@ def main():
             feats = eng.pca_batch(data, None, 8, False)["out"]
         elif kind == "hu":
             feats = eng.hu_batch(data, thresh=127, on_value=255)["hulog7"]
+        elif kind == "views+hu":
+            feats = hu2d.hu_from_clouds_device(flat, cloud_off, 12, 224)
+            sil_ms.append(0.0)
         elif kind == "sil+hu":
             masks = eng.silhouette_batch(data, 224, 0.05, True)["mask"]
             sil_ms.append(eng.profile_last_ms())   # the Hu launch below overwrites the event pair
@@ -185,6 +202,10 @@ def main():
         assert table is not None and table.shape[0] == total
     fence()
     elapsed = time.perf_counter() - t0
+    if kind == "views+hu":   # the renderer's kernel, timed on one extra call after the timed region
+        rvm = importlib.import_module("image-processing_amd.render_views")
+        rvm.render_views_device(flat, cloud_off, 12, 224)
+        kernel_ms = [eng.profile_last_ms()]
     eng.profile(False)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -202,13 +223,14 @@ def main():
                 traffic = json.loads(tfile.read_text()).get(args.workload, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        unit = "sets/s" if kind == "pca" else "images/s"
+        unit = "sets/s" if kind == "pca" else ("clouds/s" if kind == "views+hu" else "images/s")
         out = {
-            "metric": "images/sec Hu+PCA features" if kind != "pca" else "point sets/sec PCA features",
+            "metric": {"pca": "point sets/sec PCA features",
+                       "views+hu": "clouds/sec rendered views + Hu features"}.get(kind, "images/sec Hu+PCA features"),
             "value": total * args.steps / elapsed, "unit": unit, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": wl["scaling"], "vs_baseline": None,
-            "dtype": "f64" if kind == "pca" else ("u32" if kind == "sil+hu" else "int64"),
+            "dtype": "f64" if kind == "pca" else ("u32" if kind in ("sil+hu", "views+hu") else "int64"),
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {wl['desc']}", "units_per_gpu": units, "total_units": total,
                        "parallelism": f"dp{world} (units sharded, all-gather of features)" if world > 1 else "single GPU",
@@ -216,12 +238,12 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": {"pca": "pca_sets_reg_kernel", "hu": "hu_band_kernel", "hu+cpca": "hu_band_kernel",
-                                    "sil+hu": "sil_mask_kernel"}[kind],
+                                    "sil+hu": "sil_mask_kernel", "views+hu": "render_views_kernel"}[kind],
                          "kernel_ms": kavg, "units_per_launch": units},
         }
         if world == 1 and not args.no_cpu_baseline:
             cores = min(16, os.cpu_count() or 1)
-            n_s = args.cpu_sample or (cores * {"pca": 12000, "hu+cpca": 2400, "hu": 12000, "sil+hu": 400}[kind])
+            n_s = args.cpu_sample or (cores * {"pca": 12000, "hu+cpca": 2400, "hu": 12000, "sil+hu": 400, "views+hu": 16}[kind])
             n_s = min(n_s, units)
             sample = data[:n_s].cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(kind, sample, cores)

@@ -12,8 +12,9 @@
 //     integer "plain" RGBA blend onto the opaque white figure, so a pixel's
 //     value depends on the order of the markers that touch it.
 // One block per (cloud, view): the canvas lives in LDS, the block projects and
-// snaps the points in parallel, and one wave applies the stamps in point
-// order, a lane per stamp cell (LDS operations of a wave complete in order).
+// snaps the points in parallel, and every wave applies, in point order, the
+// stamps that fall into its band of canvas rows, a lane per stamp cell (LDS
+// operations of a wave complete in order).
 #include "fx_common.h"
 
 namespace {
@@ -118,12 +119,20 @@ __global__ __launch_bounds__(FX_BLOCK) void render_views_kernel(RenderArgs A)
     const double s = sx < sy ? sx : sy;
     const double offx = (dres - W * s) / 2.0, offy = (dres - H * s) / 2.0;
 
+    // Stamping: the canvas rows are split into one band per wave; a wave walks
+    // the points in order and applies the stamp cells that fall into its band,
+    // a lane per cell.  A pixel belongs to one wave, and the LDS operations of a
+    // wave complete in order, so the read-modify-write sequences on a pixel
+    // keep the point order without any barrier.
     const int K = A.K, half = K / 2;
-    const int cell_dy = t / K - half, cell_dx = t % K - half;
-    const uint32_t alpha = t < K * K ? A.stamp[t] : 0u;
+    const int lane = fx_lane(), wave = fx_wave();
+    const int cell_dy = lane / K - half, cell_dx = lane % K - half;
+    const uint32_t alpha = lane < K * K ? A.stamp[lane] : 0u;
     const uint32_t den = ((alpha + 255u) << 8) - alpha * 255u;
     const float inv_den = 1.0f / (float)den;
     const uint32_t marker = (uint32_t)A.marker;
+    const int band_rows = (res + FX_WAVES_PER_BLOCK - 1) / FX_WAVES_PER_BLOCK;
+    const int band_lo = wave * band_rows, band_hi = min(res, band_lo + band_rows);
 
     for (int64_t c0 = 0; c0 < n; c0 += RENDER_CHUNK) {
         const int m = (int)(n - c0 < RENDER_CHUNK ? n - c0 : RENDER_CHUNK);
@@ -139,12 +148,18 @@ __global__ __launch_bounds__(FX_BLOCK) void render_views_kernel(RenderArgs A)
             s_snap[i] = ((uint32_t)(row + 1024) << 16) | (uint32_t)(col + 1024);
         }
         __syncthreads();
-        if (t < FX_WAVE && alpha != 0u) {
-            for (int i = 0; i < m; i++) {
-                const uint32_t rc = s_snap[i];
+        for (int base = 0; base < m; base += FX_WAVE) {
+            const int i = base + lane;
+            const uint32_t mine = i < m ? s_snap[i] : 0u;
+            const int my_row = (int)(mine >> 16) - 1024;
+            unsigned long long todo = __ballot(i < m && my_row + half >= band_lo && my_row - half < band_hi);
+            while (todo) {
+                const int j = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const uint32_t rc = (uint32_t)__builtin_amdgcn_readlane((int)mine, j);
                 const int row = (int)(rc >> 16) - 1024 + cell_dy;
                 const int col = (int)(rc & 0xFFFFu) - 1024 + cell_dx;
-                if (row >= 0 && row < res && col >= 0 && col < res) {
+                if (alpha != 0u && row >= band_lo && row < band_hi && col >= 0 && col < res) {
                     const int at = row * res + col;
                     const uint32_t p = canvas[at];
                     canvas[at] = (uint8_t)(alpha == 255u ? marker : agg_blend(p, marker, alpha, den, inv_den));

@@ -143,6 +143,48 @@ def compute_hu_from_image(img_or_mask: np.ndarray) -> np.ndarray:
     return compute_hu_batch(np.asarray(img_or_mask).astype(np.uint8)[None])[0]
 
 
+def hu_from_clouds_device(points, offsets, views: int = 12, resolution: int = 224, point_size: float = 2.0,
+                          crop_margin: float = 0.05, preprocess_crop: bool = False, use_silhouette: bool = False,
+                          bg_color: str = "white", camera_radius_factor: float = 2.0, seed: int = 42,
+                          return_views: bool = False):
+    """hu_from_clouds for clouds already in HBM (float32 [total, 3], int64
+    offsets [B + 1]); returns a float32 device tensor [B, 14]."""
+    import torch
+    from . import engine, render_views
+    rendered = render_views.render_views_device(points, offsets, views, resolution, point_size, bg_color,
+                                                camera_radius_factor, seed)
+    B = rendered.shape[0]
+    raw = rendered.reshape(B * views, resolution, resolution)
+    sil = engine.silhouette_batch(raw, resolution, crop_margin, preprocess_crop, info=not use_silhouette)
+    target = sil["mask"] if use_silhouette else engine.gray_fit_batch(raw, sil["info"], resolution,
+                                                                      255 if bg_color == "white" else 0)
+    rows = engine.hu_batch(target)["hulog7"]
+    off = torch.arange(B + 1, dtype=torch.int64, device=points.device) * views
+    out = engine.hu_groupstat(rows, off)
+    return (out, rendered) if return_views else out
+
+
+def hu_from_clouds(clouds: Sequence[np.ndarray], views: int = 12, resolution: int = 224, point_size: float = 2.0,
+                   crop_margin: float = 0.05, preprocess_crop: bool = False, use_silhouette: bool = False,
+                   bg_color: str = "white", camera_radius_factor: float = 2.0, seed: int = 42,
+                   return_views: bool = False):
+    """Sampled clouds -> rendered views -> preprocessing -> log-Hu -> per-sample
+    mean / std, float32 [B, 14], without the views leaving the device: the
+    chain of the reference's render_views.py (its matplotlib renderer) and
+    extract_2d_hu.py (:602-667) with the PNG files in between left out (a PNG
+    of a gray view decodes to the same bytes)."""
+    from . import render_views
+    for c in clouds:
+        if c.shape[0] < 1:
+            raise ValueError("empty point cloud")
+    pts, off = render_views.pack_clouds(clouds, _device())
+    res = hu_from_clouds_device(pts, off, views, resolution, point_size, crop_margin, preprocess_crop, use_silhouette,
+                                bg_color, camera_radius_factor, seed, return_views)
+    if return_views:
+        return res[0].cpu().numpy().astype(np.float32), res[1]
+    return res.cpu().numpy().astype(np.float32)
+
+
 def save_descriptor_npy(sample_id: str, vec: np.ndarray, out_dir: Path) -> Path:
     """<id>_hu.npy, float32 (reference :481-488)."""
     ensure_dir(out_dir)

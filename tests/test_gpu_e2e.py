@@ -176,3 +176,41 @@ def test_allgather_features_on_a_one_rank_communicator(gpu):
     finally:
         rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+def test_clouds_to_hu_table_on_the_device(gpu, oracle, c_oracle, tmp_path):
+    """Clouds -> rendered views -> preprocessing -> Hu -> per-sample statistics
+    without leaving HBM equals the chain through PNG files: the oracle's
+    renderer, preprocess_image and Hu per view, float32 mean / std per sample."""
+    hu, rv = pkg("extract_2d_hu"), pkg("render_views")
+    rng = np.random.default_rng(21)
+    clouds = [(rng.normal(size=(1024, 3)) * s).astype(np.float32) for s in ([0.3, 0.25, 0.6], [0.5, 0.1, 0.2])]
+    views, res = 6, 128
+    for use_sil, crop in ((False, False), (True, True)):
+        got, rendered = hu.hu_from_clouds(clouds, views, res, use_silhouette=use_sil, preprocess_crop=crop, return_views=True)
+        assert got.shape == (2, 14) and got.dtype == np.float32
+        for b, c in enumerate(clouds):
+            p64 = c.astype(np.float64)
+            mins, maxs, cen, _ = oracle.bbox_and_center(p64)
+            poses = oracle.compute_camera_poses(views, mins, maxs, cen)
+            rows = []
+            for v in range(views):
+                img = oracle.render_view(p64, poses[v], res, rv.marker_stamp(2.0))
+                np.testing.assert_array_equal(rendered[b, v].cpu().numpy(), img)
+                pre, mask = oracle.preprocess_image(img, res, 0.05, "white", crop)
+                rows.append(c_oracle.hu_batch((mask if use_sil else pre)[None], thresh=-1)["hulog7"][0])
+            rows = np.stack(rows).astype(np.float32)
+            want = np.concatenate([rows.mean(axis=0), rows.std(axis=0)]).astype(np.float32)
+            np.testing.assert_allclose(got[b], want, rtol=1e-5, atol=1e-6, err_msg=f"cloud {b} silhouette {use_sil}")
+    # the same numbers through the files: script-rendered PNGs read by the Hu script's worker
+    sampled = tmp_path / "sampled"
+    sampled.mkdir()
+    np.save(sampled / "tree_a.npy", clouds[0])
+    assert rv.main(["--sampled_dir", str(sampled), "--out_dir", str(tmp_path / "views"), "--views", str(views),
+                    "--resolution", str(res), "--reports_dir", str(tmp_path / "rep"), "--n_preview", "0"]) == 0
+    cfg = {"out_dir": str(tmp_path / "o"), "resolution": res, "use_silhouette": False, "preprocess_crop": False,
+           "crop_margin": 0.05, "bg_color": "white", "expected_views": views, "overwrite": True,
+           "reports_dir": str(tmp_path / "rep")}
+    rec = hu.process_sample_worker(("tree_a", str(tmp_path / "views" / "tree_a"), cfg))
+    direct = hu.hu_from_clouds(clouds[:1], views, res)
+    np.testing.assert_array_equal(np.asarray(rec["vec"], dtype=np.float32), direct[0])
