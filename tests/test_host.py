@@ -377,3 +377,37 @@ def test_band_ranges_and_limbs():
     for v in vals:
         acc = [a + b for a, b in zip(acc, fxd.to_limbs(v))]
     assert fxd.from_limbs(acc) == sum(vals) and max(acc) < 1 << 63
+
+
+# ------------------------------------------------------------ renderer / thresholds host logic
+def test_camera_table_matches_the_per_cloud_poses():
+    """The vectorised camera table (all clouds at once) against the oracle's
+    per-cloud, per-view restatement of compute_camera_poses and the camera basis."""
+    from oracle import cpu_ref
+    rv = pkg("render_views")
+    rng = np.random.default_rng(3)
+    bounds, want_cam, want_scale = [], [], []
+    for n in (1, 5, 1024):
+        pts = (rng.normal(size=(n, 3)) * rng.uniform(0.1, 5, size=3) + rng.normal(size=3) * 4).astype(np.float32).astype(np.float64)
+        mins, maxs, cen, diag = cpu_ref.bbox_and_center(pts)
+        bounds.append(np.concatenate([mins, maxs, cen]))
+        poses = cpu_ref.compute_camera_poses(12, mins, maxs, cen, 2.0, 42)
+        mine = rv.compute_camera_poses(12, mins, maxs, cen, 2.0, 42)
+        for a, b in zip(mine, poses):
+            np.testing.assert_array_equal(a["position"], b["position"])
+        want_cam.append(np.stack([np.concatenate([*cpu_ref.camera_plane(p), p["lookat"]]) for p in poses]))
+        want_scale.append((224 * 0.35) / (diag if diag >= 1e-9 else 1.0))
+    cam, scale = rv.camera_table(np.stack(bounds), 12, 224)
+    assert cam.shape == (3, 12, 9) and cam.flags.c_contiguous
+    np.testing.assert_allclose(cam, np.stack(want_cam), rtol=0, atol=1e-14)
+    np.testing.assert_allclose(scale, want_scale, rtol=1e-15)
+    assert [len(rv.view_angles(v)) for v in (1, 2, 3, 7, 12)] == [1, 2, 3, 7, 12]
+    assert rv.marker_stamp(2.0).shape == (3, 3) and rv.marker_stamp(0.5).shape == (1, 1)
+    with pytest.raises(ValueError):
+        rv.marker_stamp(2.5)
+
+
+def test_class_codes_follow_sorted_labels():
+    b = pkg("binarize")
+    classes, codes = b.class_codes(np.array(["oak", "ash", "oak", "fir"]))
+    assert classes == ["ash", "fir", "oak"] and codes.tolist() == [2, 0, 2, 1] and codes.dtype == np.int32
