@@ -324,7 +324,12 @@ __device__ __forceinline__ void wave_sum9(double (&v)[9], double *slab)
 template <int PPL, bool FULL, int NW>
 __global__ __launch_bounds__(FX_WAVE *NW, FX_PCA_WAVES) void pca_sets_reg_kernel(PcaArgs A)
 {
-    __shared__ uint32_t hist_all[NW][HIST_MAX];
+    // The histogram of a wave is kept in HIST_COPIES copies, lane l counting in
+    // copy l % HIST_COPIES: most points of a set fall into a few bins, and 64
+    // lanes adding to the same few LDS words serialise.  A pitch of 65 words
+    // puts the same bin of different copies into different banks.
+    constexpr int HIST_COPIES = 8, HIST_PITCH = HIST_MAX + 1;
+    __shared__ uint32_t hist_all[NW][HIST_COPIES * HIST_PITCH];
     __shared__ double red_all[NW][RED9_WORDS];
     __shared__ double cov_all[NW][6], eig_all[NW][6];
     const int lane = fx_lane(), wave = fx_wave();
@@ -334,7 +339,10 @@ __global__ __launch_bounds__(FX_WAVE *NW, FX_PCA_WAVES) void pca_sets_reg_kernel
     const int64_t set = live ? set_raw : 0;
     const int n = (int)A.N;
     uint32_t *hist = hist_all[wave];
-    hist[lane] = 0;
+#pragma unroll
+    for (int k = 0; k < HIST_COPIES; k++)
+        hist[k * HIST_PITCH + lane] = 0;
+    uint32_t *my_hist = hist + (lane % HIST_COPIES) * HIST_PITCH;
 
     constexpr int G = PPL / 4;  // 4-point groups per lane
     const float4 *g4 = reinterpret_cast<const float4 *>(A.pts + set * (int64_t)n * 3);
@@ -513,15 +521,20 @@ __global__ __launch_bounds__(FX_WAVE *NW, FX_PCA_WAVES) void pca_sets_reg_kernel
                     bin = fx_hist_bin(proj(x[i], y[i], z[i]), step, inv_step, nb);
                 else
                     bin = (int)q;
-                atomicAdd(&hist[bin], 1u);
+                atomicAdd(&my_hist[bin], 1u);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (live && lane < nb)
+        if (live && lane < nb) {
             // count / n: both are integers below 2^24, so the float32 quotient is the
             // float64 quotient rounded to float32
-            A.out[set * width + 9 + lane] = (float)hist[lane] / (float)n;
+            uint32_t h = 0;
+#pragma unroll
+            for (int k = 0; k < HIST_COPIES; k++)
+                h += hist[k * HIST_PITCH + lane];
+            A.out[set * width + 9 + lane] = (float)h / (float)n;
+        }
     } else if (live && lane < nb) {
         A.out[set * width + 9 + lane] = lane == 0 ? 1.0f : 0.0f;
     }
