@@ -272,7 +272,6 @@ __global__ __launch_bounds__(FX_WAVE *WPB) void pca_sets_wave_kernel(PcaArgs A)
 #ifndef FX_PCA_WAVES
 #define FX_PCA_WAVES 4
 #endif
-// FULL: the set has exactly 64 * PPL points, no lane holds a missing point.
 // Sum of nine float64 values over the lanes of a wave through LDS; every lane
 // receives the same nine totals (bit for bit: the lanes go on to run the same
 // eigen-solve).  Lane l < 63 adds a ninth of row l / 7; nine lanes add the seven
@@ -321,7 +320,12 @@ __device__ __forceinline__ void wave_sum9(double (&v)[9], double *slab)
 #ifndef FX_PCA_NW
 #define FX_PCA_NW 4
 #endif
-template <int PPL, bool FULL, int NW>
+// RAGGED: sets of different sizes (CSR offsets, work list) or a fixed size that
+// is not a multiple of four points / not 16-byte aligned.  Lane l then holds the
+// points l, l + 64, ... and loads them one by one (12 bytes, 768 contiguous
+// bytes per load instruction of the wave); 4 % slower than the 16-byte loads of
+// the aligned layout, where lane l holds the four-point groups l, l + 64, ...
+template <int PPL, bool RAGGED, int NW>
 __global__ __launch_bounds__(FX_WAVE *NW, FX_PCA_WAVES) void pca_sets_reg_kernel(PcaArgs A)
 {
     // The histogram of a wave is kept in HIST_COPIES copies, lane l counting in
@@ -333,31 +337,48 @@ __global__ __launch_bounds__(FX_WAVE *NW, FX_PCA_WAVES) void pca_sets_reg_kernel
     __shared__ double red_all[NW][RED9_WORDS];
     __shared__ double cov_all[NW][6], eig_all[NW][6];
     const int lane = fx_lane(), wave = fx_wave();
-    const int64_t set_raw = (int64_t)blockIdx.x * NW + wave;
-    // a wave past the last set stays for the block barriers: it works on set 0 and writes nothing
-    const bool live = set_raw < A.n_sets;
-    const int64_t set = live ? set_raw : 0;
-    const int n = (int)A.N;
+    const int64_t slot = (int64_t)blockIdx.x * NW + wave;
+    // a wave past the last set stays for the block barriers: it works on the first set and writes nothing
+    const bool in_range = slot < A.n_sets;
+    const SetView sv = resolve_set(A, in_range ? slot : 0);
+    const int64_t set = sv.set;
+    const int n = (int)sv.n;
+    const bool live = in_range && n >= 3;   // a set of fewer than three points gets a NaN row
+    if (RAGGED && in_range && n < 3)
+        write_nan_row(A, set, lane, FX_WAVE);
     uint32_t *hist = hist_all[wave];
 #pragma unroll
     for (int k = 0; k < HIST_COPIES; k++)
         hist[k * HIST_PITCH + lane] = 0;
     uint32_t *my_hist = hist + (lane % HIST_COPIES) * HIST_PITCH;
 
-    constexpr int G = PPL / 4;  // 4-point groups per lane
-    const float4 *g4 = reinterpret_cast<const float4 *>(A.pts + set * (int64_t)n * 3);
     float x[PPL], y[PPL], z[PPL];
+    constexpr int G = RAGGED ? PPL : PPL / 4;  // predicates: per point, or per 4-point group
     bool have[G];
+    if (RAGGED) {
 #pragma unroll
-    for (int k = 0; k < G; k++) {
-        const int grp = lane + FX_WAVE * k;  // points 4*grp .. 4*grp+3
-        have[k] = FULL || 4 * grp < n;       // n is a multiple of 4
-        const int gc = have[k] ? grp : 0;
-        const float4 a = g4[3 * gc], b = g4[3 * gc + 1], c = g4[3 * gc + 2];
-        x[4 * k] = a.x, y[4 * k] = a.y, z[4 * k] = a.z;
-        x[4 * k + 1] = a.w, y[4 * k + 1] = b.x, z[4 * k + 1] = b.y;
-        x[4 * k + 2] = b.z, y[4 * k + 2] = b.w, z[4 * k + 2] = c.x;
-        x[4 * k + 3] = c.y, y[4 * k + 3] = c.z, z[4 * k + 3] = c.w;
+        for (int k = 0; k < PPL; k++) {
+            const int p = lane + FX_WAVE * k;
+            have[k] = p < n;
+            x[k] = y[k] = z[k] = 0.0f;
+            if (have[k]) {
+                const float *q = sv.base + 3 * p;
+                x[k] = q[0], y[k] = q[1], z[k] = q[2];
+            }
+        }
+    } else {
+        const float4 *g4 = reinterpret_cast<const float4 *>(sv.base);
+#pragma unroll
+        for (int k = 0; k < PPL / 4; k++) {
+            const int grp = lane + FX_WAVE * k;  // points 4*grp .. 4*grp+3
+            have[k] = 4 * grp < n;               // n is a multiple of 4
+            const int gc = have[k] ? grp : 0;
+            const float4 a = g4[3 * gc], b = g4[3 * gc + 1], c = g4[3 * gc + 2];
+            x[4 * k] = a.x, y[4 * k] = a.y, z[4 * k] = a.z;
+            x[4 * k + 1] = a.w, y[4 * k + 1] = b.x, z[4 * k + 1] = b.y;
+            x[4 * k + 2] = b.z, y[4 * k + 2] = b.w, z[4 * k + 2] = c.x;
+            x[4 * k + 3] = c.y, y[4 * k + 3] = c.z, z[4 * k + 3] = c.w;
+        }
     }
     // pivot = the set's first point (lane 0, group 0)
     const float kx32 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x[0])));
@@ -368,7 +389,7 @@ __global__ __launch_bounds__(FX_WAVE *NW, FX_PCA_WAVES) void pca_sets_reg_kernel
     double D[3] = {0, 0, 0}, Q[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < PPL; i++) {
-        if (have[i >> 2]) {
+        if (have[RAGGED ? i : i >> 2]) {
             const double dx = (double)x[i] - kx, dy = (double)y[i] - ky, dz = (double)z[i] - kz;
             D[0] += dx;
             D[1] += dy;
@@ -408,7 +429,7 @@ __global__ __launch_bounds__(FX_WAVE *NW, FX_PCA_WAVES) void pca_sets_reg_kernel
         double r2 = 0.0;
 #pragma unroll
         for (int i = 0; i < PPL; i++) {
-            if (have[i >> 2]) {
+            if (have[RAGGED ? i : i >> 2]) {
                 const double dx = (double)x[i] - mx, dy = (double)y[i] - my, dz = (double)z[i] - mz;
                 r2 = fmax(r2, dx * dx + dy * dy + dz * dz);
             }
@@ -489,7 +510,7 @@ __global__ __launch_bounds__(FX_WAVE *NW, FX_PCA_WAVES) void pca_sets_reg_kernel
 #pragma unroll
     for (int i = 0; i < PPL; i++) {
         const float dx = (x[i] - kx32) - ox32, dy = (y[i] - ky32) - oy32, dz = (z[i] - kz32) - oz32;
-        p32[i] = have[i >> 2] ? fabsf(fmaf(dz, vz32, fmaf(dy, vy32, dx * vx32))) : -1.0f;
+        p32[i] = have[RAGGED ? i : i >> 2] ? fabsf(fmaf(dz, vz32, fmaf(dy, vy32, dx * vx32))) : -1.0f;
         top32 = fmaxf(top32, p32[i]);
     }
     top32 = fx_wave_max_f32_dpp(top32);
@@ -513,7 +534,7 @@ __global__ __launch_bounds__(FX_WAVE *NW, FX_PCA_WAVES) void pca_sets_reg_kernel
         const float qmax = (float)nb - margin;
 #pragma unroll
         for (int i = 0; i < PPL; i++) {
-            if (have[i >> 2]) {
+            if (have[RAGGED ? i : i >> 2]) {
                 // q within `margin` of an integer (a bin edge), or at the top edge: float64 decides
                 const float q = p32[i] * inv32;
                 int bin;
@@ -849,6 +870,33 @@ int launch_wave_kernel(PcaArgs A, int64_t max_points, hipStream_t s)
     return FX_OK;
 }
 
+constexpr int64_t REG_SET_MAX_POINTS = 1024;  // 3-D sets up to this size are kept in registers
+
+int launch_reg_sets(const PcaArgs &A, int64_t max_points, bool ragged, hipStream_t s)
+{
+    constexpr int NW = FX_PCA_NW;  // sets (waves) per block
+    const int64_t blocks = (A.n_sets + NW - 1) / NW;
+    FX_REQUIRE(blocks <= 0x7fffffffLL, "fx_pca_batch_f32: too many sets for one launch");
+    const dim3 grid((unsigned)blocks), block(FX_WAVE * NW);
+    if (ragged) {
+        if (max_points <= 256)
+            hipLaunchKernelGGL((pca_sets_reg_kernel<4, true, NW>), grid, block, 0, s, A);
+        else if (max_points <= 512)
+            hipLaunchKernelGGL((pca_sets_reg_kernel<8, true, NW>), grid, block, 0, s, A);
+        else
+            hipLaunchKernelGGL((pca_sets_reg_kernel<16, true, NW>), grid, block, 0, s, A);
+    } else {
+        if (max_points <= 256)
+            hipLaunchKernelGGL((pca_sets_reg_kernel<4, false, NW>), grid, block, 0, s, A);
+        else if (max_points <= 512)
+            hipLaunchKernelGGL((pca_sets_reg_kernel<8, false, NW>), grid, block, 0, s, A);
+        else
+            hipLaunchKernelGGL((pca_sets_reg_kernel<16, false, NW>), grid, block, 0, s, A);
+    }
+    FX_HIP_CHECK(hipGetLastError());
+    return FX_OK;
+}
+
 int launch_small_sets(const PcaArgs &A, int64_t max_points, hipStream_t s)
 {
     // keep each block's LDS near 48 KiB so that three blocks share a CU
@@ -951,20 +999,9 @@ extern "C" int fx_pca_batch_f32(const float *d_pts, const int64_t *d_offsets, in
     if (!d_offsets) {
         FxProfileScope prof(s);
         const char *force = getenv("FX_PCA_KERNEL");  // "lds": development switch
-        const bool reg_ok = dims == 3 && N >= 4 && N <= 1024 && N % 4 == 0 && (uintptr_t)d_pts % 16 == 0 &&
-                            !(force && strcmp(force, "lds") == 0);
-        if (reg_ok) {
-            constexpr int NW = FX_PCA_NW;  // sets (waves) per block
-            const dim3 grid((unsigned)((B + NW - 1) / NW)), block(FX_WAVE * NW);
-            if (N <= 256)
-                hipLaunchKernelGGL((pca_sets_reg_kernel<4, false, NW>), grid, block, 0, s, A);
-            else if (N <= 512)
-                hipLaunchKernelGGL((pca_sets_reg_kernel<8, false, NW>), grid, block, 0, s, A);
-            else
-                hipLaunchKernelGGL((pca_sets_reg_kernel<16, false, NW>), grid, block, 0, s, A);
-            FX_HIP_CHECK(hipGetLastError());
-            return FX_OK;
-        }
+        const bool reg_ok = dims == 3 && N >= 3 && N <= REG_SET_MAX_POINTS && !(force && strcmp(force, "lds") == 0);
+        if (reg_ok)
+            return launch_reg_sets(A, N, N % 4 != 0 || (uintptr_t)d_pts % 16 != 0, s);
         if (N <= WAVE_SET_MAX_POINTS)
             return launch_small_sets(A, N < 3 ? 3 : N, s);
         int32_t *sets = (int32_t *)malloc((size_t)B * sizeof(int32_t));
@@ -1013,13 +1050,24 @@ extern "C" int fx_pca_batch_f32(const float *d_pts, const int64_t *d_offsets, in
         fx_set_error("fx_pca_batch_f32: host allocation failed");
         return FX_ENOMEM;
     }
-    int64_t n_small = 0, n_large = 0, max_small = 3;
+    // work list: sets for the register kernel, then those for the LDS kernel, then the large clouds
+    const char *force = getenv("FX_PCA_KERNEL");
+    const int64_t reg_max = dims == 3 && !(force && strcmp(force, "lds") == 0) ? REG_SET_MAX_POINTS : -1;
+    int64_t n_reg = 0, n_small = 0, n_large = 0, max_reg = 3, max_small = 3;
     bool ok = true;
     for (int64_t b = 0; b < B; b++) {
         const int64_t n = h_off[b + 1] - h_off[b];
         if (n < 0)
             ok = false;
-        if (n <= WAVE_SET_MAX_POINTS) {
+        if (n <= reg_max) {
+            h_ids[n_reg++] = (int32_t)b;
+            max_reg = n > max_reg ? n : max_reg;
+        }
+    }
+    n_small = n_reg;
+    for (int64_t b = 0; b < B; b++) {
+        const int64_t n = h_off[b + 1] - h_off[b];
+        if (n > reg_max && n <= WAVE_SET_MAX_POINTS) {
             h_ids[n_small++] = (int32_t)b;
             max_small = n > max_small ? n : max_small;
         }
@@ -1059,10 +1107,16 @@ extern "C" int fx_pca_batch_f32(const float *d_pts, const int64_t *d_offsets, in
 
     FxProfileScope prof(s);
     int rc = FX_OK;
-    if (n_small > 0) {
+    if (n_reg > 0) {
         PcaArgs S = A;
         S.set_ids = d_ids;
-        S.n_sets = n_small;
+        S.n_sets = n_reg;
+        rc = launch_reg_sets(S, max_reg, true, s);
+    }
+    if (rc == FX_OK && n_small > n_reg) {
+        PcaArgs S = A;
+        S.set_ids = d_ids + n_reg;
+        S.n_sets = n_small - n_reg;
         rc = launch_small_sets(S, max_small, s);
     }
     if (rc == FX_OK && n_large > 0)

@@ -137,6 +137,20 @@ if __name__ == "__main__":
             torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3 * 1e3
             eng.profile(True); rv.render_views_device(pts, off, V, res); k = eng.profile_last_ms(); eng.profile(False)
             print(f"render B={B} N={N} V={V} {res}px: {dt:.2f} ms per call ({B*V/dt:.0f} k views/s), kernel {k:.2f} ms", flush=True)
+    elif what == "pcar":
+        import numpy as np
+        rng = np.random.default_rng(0)
+        for lo, hi, B in ((500, 1024, 300000), (3, 256, 1000000), (1025, 2048, 100000)):
+            sizes = rng.integers(lo, hi + 1, B)
+            off = np.zeros(B + 1, dtype=np.int64); np.cumsum(sizes, out=off[1:])
+            pts = torch.randn((int(off[-1]), 3), dtype=torch.float32, device=dev)
+            d_off = torch.from_numpy(off).to(dev)
+            for _ in range(2): eng.pca_batch(pts, d_off)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5): eng.pca_batch(pts, d_off)
+            torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5 * 1e3
+            print(f"pca ragged B={B} sizes {lo}..{hi}: {dt:.3f} ms per call  {off[-1]*12/dt/1e6:.0f} GB/s", flush=True)
     elif what == "sil1":
         ms, gbps = time_sil(20000, 224, 224, 224, reps=3)
         print(f"sil B=20000 224x224->224: {ms:.3f} ms  {gbps:.0f} GB/s", flush=True)
