@@ -994,6 +994,7 @@ extern "C" int fx_silhouette_batch_u8(const uint8_t *d_img, int64_t B, int H, in
 namespace {
 
 constexpr int FIT_PRECISION_BITS = 32 - 8 - 2;
+constexpr int FIT_UNROLL = 8;
 constexpr int FIT_MAX_COEFFS = 4 * SIL_MAX_SIDE + 5 * SIL_MAX_SIDE;  // outSize * ksize never exceeds this
 
 struct FitArgs {
@@ -1043,6 +1044,8 @@ __device__ void fit_coeffs(int in_size, int out_size, int ksize, double scale, d
             kk[x] = w < 0 ? (int)(-0.5 + w * (double)(1 << FIT_PRECISION_BITS))
                           : (int)(0.5 + w * (double)(1 << FIT_PRECISION_BITS));
         }
+        for (int x = xmax; x < ksize; x++)
+            kk[x] = 0;  // the fixed-length tap loops run over all ksize entries
         lo[xx] = (uint16_t)xmin;
         cnt[xx] = (uint16_t)xmax;
     }
@@ -1097,7 +1100,38 @@ __global__ __launch_bounds__(FX_BLOCK) void gray_fit_kernel(FitArgs A)
 
         const uint8_t *src = A.img + b * A.stride + (int64_t)y0 * A.pitch + x0;
         // pass along x: temp[y][xx], ch rows of nw pixels
-        if (horiz) {
+        // The common case (no reduction: five taps per axis) takes FIT_UNROLL pixels
+        // per thread and step with every load issued before the first use: one
+        // pixel and one tap at a time, a thread waits a memory latency per tap.
+        if (horiz && kxs == 5) {
+            const int total = ch * nw;
+            for (int i0 = t; i0 < total; i0 += FX_BLOCK * FIT_UNROLL) {
+                int v[FIT_UNROLL][5], kofs[FIT_UNROLL];
+#pragma unroll
+                for (int u = 0; u < FIT_UNROLL; u++) {
+                    const int i = i0 + u * FX_BLOCK;
+                    const int ic = i < total ? i : 0;
+                    const int y = ic / nw, xx = ic - y * nw;
+                    const uint8_t *p = src + (int64_t)y * A.pitch + s_xlo[xx];
+                    const int n = s_xcnt[xx];
+                    kofs[u] = xx * 5;
+#pragma unroll
+                    for (int j = 0; j < 5; j++)
+                        v[u][j] = p[j < n ? j : n - 1];  // taps beyond n have a zero coefficient
+                }
+#pragma unroll
+                for (int u = 0; u < FIT_UNROLL; u++) {
+                    int acc = 1 << (FIT_PRECISION_BITS - 1);
+#pragma unroll
+                    for (int j = 0; j < 5; j++)
+                        acc += __mul24(v[u][j], s_kx[kofs[u] + j]);
+                    if (i0 + u * FX_BLOCK < total)
+                        temp[i0 + u * FX_BLOCK] = fit_clip8(acc);
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+        } else if (horiz) {
             for (int i = t; i < ch * nw; i += FX_BLOCK) {
                 const int y = i / nw, xx = i - y * nw;
                 const uint8_t *p = src + (int64_t)y * A.pitch + s_xlo[xx];
@@ -1114,7 +1148,77 @@ __global__ __launch_bounds__(FX_BLOCK) void gray_fit_kernel(FitArgs A)
         // pass along y and paste
         const int px0 = (res - nw) / 2, py0 = (res - nh) / 2;
         uint8_t *out = A.out + b * (int64_t)res * res;
-        for (int i = t; i < res * res; i += FX_BLOCK) {
+        if (!horiz && !vert) {
+            // The crop already has the target size (e.g. uncropped views at the working
+            // resolution): a copy with a background frame.  A thread takes 16 pixels of
+            // a row so that its 16 loads are in flight together; one pixel per step
+            // would cost a memory latency per pixel.
+            const int cpr = (res + 15) >> 4;
+            for (int it = t; it < res * cpr; it += FX_BLOCK) {
+                const int Y = it / cpr, X0 = (it - Y * cpr) << 4;
+                const int yy = Y - py0;
+                const bool row_in = yy >= 0 && yy < nh;
+                const uint8_t *srow = src + (int64_t)(row_in ? yy : 0) * A.pitch;
+                uint32_t v[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const int xx = X0 + k - px0;
+                    v[k] = srow[xx < 0 ? 0 : (xx > nw - 1 ? nw - 1 : xx)];
+                }
+                uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const int xx = X0 + k - px0;
+                    const uint32_t px = (row_in && xx >= 0 && xx < nw) ? v[k] : (uint32_t)A.bg;
+                    w[k >> 2] |= px << (8 * (k & 3));
+                }
+                uint8_t *o = out + Y * res + X0;
+                if (X0 + 16 <= res && ((uintptr_t)o & 3) == 0) {
+                    uint32_t *o4 = reinterpret_cast<uint32_t *>(o);
+                    o4[0] = w[0], o4[1] = w[1], o4[2] = w[2], o4[3] = w[3];
+                } else {
+                    for (int k = 0; k < 16 && X0 + k < res; k++)
+                        o[k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+                }
+            }
+            continue;
+        }
+        const bool fast_y = !vert || kys == 5;
+        for (int i0 = t; fast_y && i0 < res * res; i0 += FX_BLOCK * FIT_UNROLL) {
+            int v[FIT_UNROLL][5], kofs[FIT_UNROLL];
+            bool inside[FIT_UNROLL];
+#pragma unroll
+            for (int u = 0; u < FIT_UNROLL; u++) {
+                const int i = i0 + u * FX_BLOCK;
+                const int ic = i < res * res ? i : 0;
+                const int Y = ic / res, X = ic - Y * res;
+                int yy = Y - py0, xx = X - px0;
+                inside[u] = yy >= 0 && yy < nh && xx >= 0 && xx < nw;
+                yy = inside[u] ? yy : 0;
+                xx = inside[u] ? xx : 0;
+                const int n = vert ? (int)s_ycnt[yy] : 1, lo = vert ? (int)s_ylo[yy] : yy;
+                kofs[u] = yy * 5;
+#pragma unroll
+                for (int j = 0; j < 5; j++) {
+                    const int r = lo + (j < n ? j : n - 1);
+                    v[u][j] = (!vert && j > 0) ? 0 : horiz ? (int)temp[r * nw + xx] : (int)src[(int64_t)r * A.pitch + xx];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < FIT_UNROLL; u++) {
+                int val = v[u][0];
+                if (vert) {
+                    int acc = 1 << (FIT_PRECISION_BITS - 1);
+#pragma unroll
+                    for (int j = 0; j < 5; j++)
+                        acc += __mul24(v[u][j], s_ky[kofs[u] + j]);
+                    val = fit_clip8(acc);
+                }
+                if (i0 + u * FX_BLOCK < res * res)
+                    out[i0 + u * FX_BLOCK] = (uint8_t)(inside[u] ? val : A.bg);
+            }
+        }
+        for (int i = t; !fast_y && i < res * res; i += FX_BLOCK) {
             const int Y = i / res, X = i - Y * res;
             const int yy = Y - py0, xx = X - px0;
             int v = A.bg;
@@ -1125,14 +1229,14 @@ __global__ __launch_bounds__(FX_BLOCK) void gray_fit_kernel(FitArgs A)
                     int acc = 1 << (FIT_PRECISION_BITS - 1);
                     if (horiz) {
                         for (int j = 0; j < n; j++)
-                            acc += __mul24((int)((volatile uint8_t *)temp)[(lo + j) * nw + xx], k[j]);
+                            acc += __mul24((int)temp[(lo + j) * nw + xx], k[j]);
                     } else {
                         for (int j = 0; j < n; j++)
                             acc += __mul24((int)src[(int64_t)(lo + j) * A.pitch + xx], k[j]);
                     }
                     v = fit_clip8(acc);
                 } else {
-                    v = horiz ? ((volatile uint8_t *)temp)[yy * nw + xx] : src[(int64_t)yy * A.pitch + xx];
+                    v = horiz ? temp[yy * nw + xx] : src[(int64_t)yy * A.pitch + xx];
                 }
             }
             out[i] = (uint8_t)v;
