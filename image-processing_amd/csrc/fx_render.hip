@@ -22,6 +22,11 @@ namespace {
 constexpr int RENDER_MAX_K = 7;        // stamps up to 7 x 7 cells (49 lanes of the stamping wave)
 constexpr int RENDER_CHUNK = 2048;     // snapped positions kept in LDS at a time
 constexpr int RENDER_MAX_RES = 384;    // canvas bytes in LDS: 384^2 = 144 KiB
+#ifndef RENDER_WAVES_N
+#define RENDER_WAVES_N 8
+#endif
+constexpr int RENDER_WAVES = RENDER_WAVES_N;  // waves per block (a power of two): the stamping runs RENDER_WAVES-fold parallel
+constexpr int RENDER_THREADS = RENDER_WAVES * FX_WAVE;
 
 struct RenderArgs {
     const float *pts;         // [total][3]
@@ -46,7 +51,7 @@ __device__ __forceinline__ double block_minmax(double v, bool is_max, double *re
     __syncthreads();
     double r = red[0];
 #pragma unroll
-    for (int w = 1; w < FX_WAVES_PER_BLOCK; w++)
+    for (int w = 1; w < RENDER_WAVES; w++)
         r = is_max ? fmax(r, red[w]) : fmin(r, red[w]);
     return r;
 }
@@ -67,10 +72,10 @@ __device__ __forceinline__ uint32_t agg_blend(uint32_t p, uint32_t c, uint32_t a
     return q;
 }
 
-__global__ __launch_bounds__(FX_BLOCK) void render_views_kernel(RenderArgs A)
+__global__ __launch_bounds__(RENDER_THREADS) void render_views_kernel(RenderArgs A)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    __shared__ double s_red[FX_WAVES_PER_BLOCK];
+    __shared__ double s_red[RENDER_WAVES];
     __shared__ uint32_t s_snap[RENDER_CHUNK];
     uint8_t *canvas = lds_raw;
     const int t = threadIdx.x;
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(FX_BLOCK) void render_views_kernel(RenderArgs A)
     const double cx = cam[6], cy = cam[7], cz = cam[8];
     const double scale = A.scale[b];
 
-    for (int i = t * 4; i < npx; i += FX_BLOCK * 4) {
+    for (int i = t * 4; i < npx; i += RENDER_THREADS * 4) {
         if (i + 4 <= npx)
             *reinterpret_cast<uint32_t *>(canvas + i) = 0xFFFFFFFFu;
         else
@@ -101,7 +106,7 @@ __global__ __launch_bounds__(FX_BLOCK) void render_views_kernel(RenderArgs A)
     };
     const double inf = __builtin_inf();
     double xmin = inf, xmax = -inf, ymin = inf, ymax = -inf;
-    for (int64_t i = t; i < n; i += FX_BLOCK) {
+    for (int64_t i = t; i < n; i += RENDER_THREADS) {
         double X, Y;
         plane(i, X, Y);
         xmin = fmin(xmin, X), xmax = fmax(xmax, X);
@@ -119,11 +124,13 @@ __global__ __launch_bounds__(FX_BLOCK) void render_views_kernel(RenderArgs A)
     const double s = sx < sy ? sx : sy;
     const double offx = (dres - W * s) / 2.0, offy = (dres - H * s) / 2.0;
 
-    // Stamping: the canvas rows are split into one band per wave; a wave walks
-    // the points in order and applies the stamp cells that fall into its band,
-    // a lane per cell.  A pixel belongs to one wave, and the LDS operations of a
-    // wave complete in order, so the read-modify-write sequences on a pixel
-    // keep the point order without any barrier.
+    // Stamping: the canvas rows are dealt to the waves in stripes of 8 rows
+    // (stripe s to wave s % RENDER_WAVES: an object in the middle of the view loads all
+    // waves alike); a wave walks the points in order and applies the stamp
+    // cells that fall into its stripes, a lane per cell.  A pixel belongs to one
+    // wave, and the LDS operations of a wave complete in order, so the
+    // read-modify-write sequences on a pixel keep the point order without any
+    // barrier.
     const int K = A.K, half = K / 2;
     const int lane = fx_lane(), wave = fx_wave();
     const int cell_dy = lane / K - half, cell_dx = lane % K - half;
@@ -131,13 +138,12 @@ __global__ __launch_bounds__(FX_BLOCK) void render_views_kernel(RenderArgs A)
     const uint32_t den = ((alpha + 255u) << 8) - alpha * 255u;
     const float inv_den = 1.0f / (float)den;
     const uint32_t marker = (uint32_t)A.marker;
-    const int band_rows = (res + FX_WAVES_PER_BLOCK - 1) / FX_WAVES_PER_BLOCK;
-    const int band_lo = wave * band_rows, band_hi = min(res, band_lo + band_rows);
+    auto owner = [](int row) -> int { return (row >> 3) & (RENDER_WAVES - 1); };  // of rows >= -1024
 
     for (int64_t c0 = 0; c0 < n; c0 += RENDER_CHUNK) {
         const int m = (int)(n - c0 < RENDER_CHUNK ? n - c0 : RENDER_CHUNK);
         __syncthreads();
-        for (int i = t; i < m; i += FX_BLOCK) {
+        for (int i = t; i < m; i += RENDER_THREADS) {
             double X, Y;
             plane(c0 + i, X, Y);
             const double px = offx + (X - x0) * s;
@@ -152,14 +158,15 @@ __global__ __launch_bounds__(FX_BLOCK) void render_views_kernel(RenderArgs A)
             const int i = base + lane;
             const uint32_t mine = i < m ? s_snap[i] : 0u;
             const int my_row = (int)(mine >> 16) - 1024;
-            unsigned long long todo = __ballot(i < m && my_row + half >= band_lo && my_row - half < band_hi);
+            // a stamp of at most 7 rows touches one or two stripes
+            unsigned long long todo = __ballot(i < m && (owner(my_row - half + 1024) == wave || owner(my_row + half + 1024) == wave));
             while (todo) {
                 const int j = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
                 const uint32_t rc = (uint32_t)__builtin_amdgcn_readlane((int)mine, j);
                 const int row = (int)(rc >> 16) - 1024 + cell_dy;
                 const int col = (int)(rc & 0xFFFFu) - 1024 + cell_dx;
-                if (alpha != 0u && row >= band_lo && row < band_hi && col >= 0 && col < res) {
+                if (alpha != 0u && row >= 0 && row < res && owner(row) == wave && col >= 0 && col < res) {
                     const int at = row * res + col;
                     const uint32_t p = canvas[at];
                     canvas[at] = (uint8_t)(alpha == 255u ? marker : agg_blend(p, marker, alpha, den, inv_den));
@@ -170,10 +177,10 @@ __global__ __launch_bounds__(FX_BLOCK) void render_views_kernel(RenderArgs A)
     __syncthreads();
     uint8_t *out = A.out + bv * (int64_t)npx;
     if ((npx & 15) == 0 && ((uintptr_t)out & 15) == 0) {
-        for (int i = t * 16; i < npx; i += FX_BLOCK * 16)
+        for (int i = t * 16; i < npx; i += RENDER_THREADS * 16)
             *reinterpret_cast<uint4 *>(out + i) = *reinterpret_cast<const uint4 *>(canvas + i);
     } else {
-        for (int i = t; i < npx; i += FX_BLOCK)
+        for (int i = t; i < npx; i += RENDER_THREADS)
             out[i] = canvas[i];
     }
 }
@@ -271,7 +278,7 @@ extern "C" int fx_render_views_u8(const float *d_pts, const int64_t *d_offsets, 
     if (lds > 48 * 1024)
         FX_HIP_CHECK(hipFuncSetAttribute((const void *)render_views_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     FxProfileScope prof((hipStream_t)stream);
-    hipLaunchKernelGGL(render_views_kernel, dim3((unsigned)(B * V)), dim3(FX_BLOCK), lds, (hipStream_t)stream, A);
+    hipLaunchKernelGGL(render_views_kernel, dim3((unsigned)(B * V)), dim3(RENDER_THREADS), lds, (hipStream_t)stream, A);
     FX_HIP_CHECK(hipGetLastError());
     return FX_OK;
 }
