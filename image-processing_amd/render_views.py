@@ -292,10 +292,18 @@ def render_samples(tasks: Sequence[Tuple]) -> List[Dict[str, Any]]:
         _, _, resolution, views, point_size, bg_color, transparent, _, radius_factor, seed, _, _ = tasks[todo[0][0]]
         imgs = render_views_batch([item[1] for item in todo], views, resolution, point_size, bg_color, radius_factor,
                                   seed).cpu().numpy()
-        for item, stack in zip(todo, imgs):
-            for v in item[3]:
-                rgb = Image.fromarray(np.repeat(stack[v][:, :, None], 3, axis=2), mode="RGB")
-                save_image(rgb if bg_color == "white" else rgb.convert("RGBA"), item[2][v], transparent)
+        # PNG encoding is the slow part of a run (zlib on the host): on the ingest thread pool
+        from . import ingest
+
+        def write(job):
+            gray, path = job
+            rgb = Image.fromarray(np.repeat(gray[:, :, None], 3, axis=2), mode="RGB")
+            save_image(rgb if bg_color == "white" else rgb.convert("RGBA"), path, transparent)
+
+        jobs = [(stack[v], item[2][v]) for item, stack in zip(todo, imgs) for v in item[3]]
+        for ok, err in ingest.map_ordered(write, jobs, ingest.default_workers()):
+            if not ok:
+                raise err
     for k, pts, names, need, rec in loaded:
         rec["views_dir"], rec["n_views"] = str(names[0].parent.resolve()), len(names)
         rec["note"], rec["rendered_timestamp"] = "ok", _now()
