@@ -46,6 +46,7 @@ SIGNATURES = {
                                          c_void_p, c_void_p, c_void_p, c_void_p]),
     "fx_binarize_ge_f64": (c_int, [c_void_p, c_i64, c_int, c_i64, c_void_p, c_void_p, c_void_p]),
     "fx_cloud_bounds_f32": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
+    "fx_camera_table_f64": (c_int, [c_void_p, c_i64, c_int, c_void_p, ctypes.c_double, c_int, c_void_p, c_void_p, c_void_p]),
     "fx_render_views_u8": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
                                    c_void_p, c_void_p]),
     "fx_synth_shapes_u8": (c_int, [c_void_p, c_i64, c_int, c_int, c_i64, c_i64, c_u64, c_i64, c_void_p]),

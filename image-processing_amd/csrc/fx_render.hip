@@ -234,7 +234,107 @@ __global__ __launch_bounds__(FX_BLOCK) void cloud_bounds_kernel(const float *pts
     }
 }
 
+constexpr int RENDER_MAX_VIEWS = 64;
+
+struct CamArgs {
+    const double *bounds;  // [B][9]: min, max, mean
+    int64_t B;
+    int V;
+    double radius_factor;
+    double res_scale;      // resolution * 0.35
+    double trig[RENDER_MAX_VIEWS][4];  // per view: cos(elevation), sin(elevation), cos(azimuth), sin(azimuth)
+    double *cam;           // [B][V][9]
+    double *scale;         // [B]
+};
+
+struct Vec3 {
+    double x, y, z;
+};
+__device__ __forceinline__ double norm3(const Vec3 &v) { return sqrt((v.x * v.x + v.y * v.y) + v.z * v.z); }
+__device__ __forceinline__ Vec3 cross3(const Vec3 &a, const Vec3 &b)
+{
+    return Vec3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+
+// Camera poses (reference compute_camera_poses :93-164) and the in-plane basis
+// of the renderer (:306-320) for every (cloud, view), one thread each, in the
+// float64 operation order of the host mirror (render_views.camera_table).
+__global__ __launch_bounds__(FX_BLOCK) void camera_table_kernel(CamArgs A)
+{
+    const int64_t i = (int64_t)blockIdx.x * FX_BLOCK + threadIdx.x;
+    if (i >= A.B * A.V)
+        return;
+    const int64_t b = i / A.V;
+    const int v = (int)(i - b * A.V);
+    const double *bd = A.bounds + b * 9;
+    const Vec3 ext{bd[3] - bd[0], bd[4] - bd[1], bd[5] - bd[2]};
+    const Vec3 cen{bd[6], bd[7], bd[8]};
+    const double diag = norm3(ext);
+    const double radius = diag > 1e-9 ? diag * A.radius_factor : A.radius_factor;
+    const double cel = A.trig[v][0], sel = A.trig[v][1], caz = A.trig[v][2], saz = A.trig[v][3];
+    const Vec3 pos{(radius * cel) * caz + cen.x, (radius * cel) * saz + cen.y, radius * sel + cen.z};
+    Vec3 fwd{cen.x - pos.x, cen.y - pos.y, cen.z - pos.z};
+    if (norm3(fwd) < 1e-9)
+        fwd = Vec3{0.0, 0.0, 1.0};
+    {
+        const double n = norm3(fwd);
+        fwd = Vec3{fwd.x / n, fwd.y / n, fwd.z / n};
+    }
+    const Vec3 up = fabs(fwd.z) > 0.999 ? Vec3{0.0, 1.0, 0.0} : Vec3{0.0, 0.0, 1.0};
+    // the renderer's basis from (position, look-at, up)
+    Vec3 f{cen.x - pos.x, cen.y - pos.y, cen.z - pos.z};
+    if (norm3(f) < 1e-12)
+        f = Vec3{0.0, 0.0, 1.0};
+    {
+        const double n = norm3(f);
+        f = Vec3{f.x / n, f.y / n, f.z / n};
+    }
+    Vec3 right = cross3(f, up);
+    if (norm3(right) < 1e-9)
+        right = cross3(f, Vec3{0.0, 1.0, 0.0});
+    {
+        const double n = norm3(right) + 1e-12;
+        right = Vec3{right.x / n, right.y / n, right.z / n};
+    }
+    Vec3 tup = cross3(right, f);
+    {
+        const double n = norm3(tup) + 1e-12;
+        tup = Vec3{tup.x / n, tup.y / n, tup.z / n};
+    }
+    double *o = A.cam + i * 9;
+    o[0] = right.x, o[1] = right.y, o[2] = right.z;
+    o[3] = tup.x, o[4] = tup.y, o[5] = tup.z;
+    o[6] = cen.x, o[7] = cen.y, o[8] = cen.z;
+    if (v == 0)
+        A.scale[b] = A.res_scale / (diag < 1e-9 ? 1.0 : diag);
+}
+
 }  // namespace
+
+extern "C" int fx_camera_table_f64(const double *d_bounds, int64_t B, int V, const double *h_trig, double radius_factor,
+                                   int resolution, double *d_cam, double *d_scale, void *stream)
+{
+    FX_REQUIRE(B >= 0 && V >= 1 && V <= RENDER_MAX_VIEWS, "fx_camera_table_f64: %lld clouds x %d views (at most %d views)",
+               (long long)B, V, RENDER_MAX_VIEWS);
+    if (B == 0)
+        return FX_OK;
+    FX_REQUIRE(d_bounds && h_trig && d_cam && d_scale, "fx_camera_table_f64: NULL argument");
+    CamArgs A;
+    A.bounds = d_bounds;
+    A.B = B;
+    A.V = V;
+    A.radius_factor = radius_factor;
+    A.res_scale = (double)resolution * 0.35;
+    for (int v = 0; v < RENDER_MAX_VIEWS; v++)
+        for (int k = 0; k < 4; k++)
+            A.trig[v][k] = v < V ? h_trig[v * 4 + k] : 0.0;
+    A.cam = d_cam;
+    A.scale = d_scale;
+    const int64_t total = B * V;
+    hipLaunchKernelGGL(camera_table_kernel, dim3((unsigned)((total + FX_BLOCK - 1) / FX_BLOCK)), dim3(FX_BLOCK), 0, (hipStream_t)stream, A);
+    FX_HIP_CHECK(hipGetLastError());
+    return FX_OK;
+}
 
 extern "C" int fx_cloud_bounds_f32(const float *d_pts, const int64_t *d_offsets, int64_t B, double *d_bounds, void *stream)
 {

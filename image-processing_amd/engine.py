@@ -335,6 +335,28 @@ def cloud_bounds(points: torch.Tensor, offsets: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def camera_table(bounds: torch.Tensor, trig, radius_factor: float, resolution: int):
+    """Camera table of B clouds on the device from their bounds (float64
+    [B, 9], cloud_bounds) and the per-view cos/sin table (host, [V, 4]):
+    (cam float64 [B, V, 9], scale float64 [B]).  Reference:
+    compute_camera_poses, src/preprocessing/render_views.py:93-164, and the
+    camera basis of render_fallback_matplotlib :306-320."""
+    import numpy as np
+    _require_cuda(bounds, "bounds")
+    if bounds.dtype != torch.float64 or bounds.dim() != 2 or bounds.shape[1] != 9 or not bounds.is_contiguous():
+        raise ValueError("bounds must be contiguous float64 [B, 9]")
+    tr = np.ascontiguousarray(trig, dtype=np.float64)
+    if tr.ndim != 2 or tr.shape[1] != 4:
+        raise ValueError("trig must be [V, 4]")
+    stream = _enter(bounds.device)
+    B, V = int(bounds.shape[0]), int(tr.shape[0])
+    cam = torch.empty((B, V, 9), dtype=torch.float64, device=bounds.device)
+    scale = torch.empty((B,), dtype=torch.float64, device=bounds.device)
+    _lib.call("fx_camera_table_f64", bounds.data_ptr(), B, V, tr.ctypes.data, float(radius_factor), int(resolution),
+              cam.data_ptr(), scale.data_ptr(), stream)
+    return cam, scale
+
+
 def render_views(points: torch.Tensor, offsets: torch.Tensor, cam: torch.Tensor, scale: torch.Tensor, resolution: int,
                  stamp, marker_value: int = 0) -> torch.Tensor:
     """uint8 [B, V, res, res] views of B clouds (layout as cloud_bounds) from

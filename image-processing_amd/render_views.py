@@ -126,6 +126,16 @@ def plane_basis(position: np.ndarray, lookat: np.ndarray, up: np.ndarray) -> np.
     return np.concatenate([right, true_up, np.broadcast_to(lookat, right.shape)], axis=-1)
 
 
+def view_trig(n_views: int, seed: int = 42, elevation_levels: Optional[Sequence[float]] = None) -> np.ndarray:
+    """[V, 4] = cos(elevation), sin(elevation), cos(azimuth), sin(azimuth) of the
+    poses, computed with math.* as the reference computes them (:134-139)."""
+    out = np.empty((n_views, 4), dtype=np.float64)
+    for v, (elev, az) in enumerate(view_angles(n_views, seed, elevation_levels)):
+        el_rad, az_rad = math.radians(elev), math.radians(az)
+        out[v] = (math.cos(el_rad), math.sin(el_rad), math.cos(az_rad), math.sin(az_rad))
+    return out
+
+
 def camera_table(bounds: np.ndarray, n_views: int, resolution: int, radius_factor: float = 2.0, seed: int = 42,
                  elevation_levels: Optional[Sequence[float]] = None):
     """Camera table of B clouds from their bounds [B, 9] (min, max, mean):
@@ -175,11 +185,15 @@ def render_views_device(points: torch.Tensor, offsets: torch.Tensor, views: int 
                         seed: int = 42) -> torch.Tensor:
     """uint8 [B, views, res, res] (device) for clouds already in HBM; every cloud
     must hold at least one point."""
-    bounds = engine.cloud_bounds(points, offsets).cpu().numpy()
-    cam, scale = camera_table(bounds, views, resolution, camera_radius_factor, seed)
-    dev = points.device
-    return engine.render_views(points, offsets, torch.from_numpy(cam).to(dev), torch.from_numpy(scale).to(dev), resolution,
-                               marker_stamp(point_size), 0 if bg_color == "white" else 255)
+    bounds = engine.cloud_bounds(points, offsets)
+    if views <= 64:
+        # poses and camera bases on the device: no host round trip inside the chain
+        cam, scale = engine.camera_table(bounds, view_trig(views, seed), camera_radius_factor, resolution)
+    else:
+        cam_h, scale_h = camera_table(bounds.cpu().numpy(), views, resolution, camera_radius_factor, seed)
+        cam, scale = torch.from_numpy(cam_h).to(points.device), torch.from_numpy(scale_h).to(points.device)
+    return engine.render_views(points, offsets, cam, scale, resolution, marker_stamp(point_size),
+                               0 if bg_color == "white" else 255)
 
 
 def render_views_batch(clouds: Sequence[np.ndarray], views: int = 12, resolution: int = 224, point_size: float = 2.0,

@@ -324,6 +324,22 @@ int fx_binarize_ge_f64(const double *d_x, int64_t rows, int cols,
  */
 int fx_cloud_bounds_f32(const float *d_pts, const int64_t *d_offsets, int64_t B,
                         double *d_bounds, void *stream);
+/*
+ * Camera table for fx_render_views_u8 on the device, so that a batch needs no
+ * host round trip between fx_cloud_bounds_f32 and the renderer:
+ * compute_camera_poses :93-164 (radius = radius_factor * bbox diagonal, camera
+ * on the ring of view v, looking at the centroid, z up unless the view axis is
+ * within 0.999 of it) and the in-plane basis of render_fallback_matplotlib
+ * :306-320, per (cloud, view).  h_trig (host): V x 4 doubles = cos(elevation),
+ * sin(elevation), cos(azimuth), sin(azimuth) of every view, computed by the
+ * caller with the C library as the reference does (math.cos / math.sin; the
+ * azimuth jitter comes from its RandomState).  V <= 64.
+ * d_cam [B, V, 9], d_scale [B] = (resolution * 0.35) / bbox diagonal.
+ */
+int fx_camera_table_f64(const double *d_bounds, int64_t B, int V,
+                        const double *h_trig, double radius_factor,
+                        int resolution, double *d_cam, double *d_scale,
+                        void *stream);
 int fx_render_views_u8(const float *d_pts, const int64_t *d_offsets, int64_t B,
                        int V, const double *d_cam, const double *d_scale,
                        int resolution, const uint8_t *stamp, int K,

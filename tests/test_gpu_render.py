@@ -62,6 +62,14 @@ def test_bounds_poses_and_errors(gpu, oracle):
     for k, c in enumerate(clouds):
         mins, maxs, cen, _ = oracle.bbox_and_center(c.astype(np.float64))
         np.testing.assert_array_equal(b[k], np.concatenate([mins, maxs, cen]))
+    # the camera table computed on the device is the host's, bit for bit (same float64 operations)
+    flat = np.stack([np.array([0.5, -1.0, 2.0] * 3), np.concatenate([[-1.0, 0, 0], [1.0, 0, 0], [0.0, 0, 0]])])
+    for views in (1, 5, 12, 64):
+        hb = np.concatenate([b, flat])              # + a single point and a line along x
+        cam_h, scale_h = rv.camera_table(hb, views, 224, 2.0, 42)
+        cam_d, scale_d = eng.camera_table(torch.from_numpy(hb).to(gpu), rv.view_trig(views, 42), 2.0, 224)
+        np.testing.assert_array_equal(cam_d.cpu().numpy(), cam_h)
+        np.testing.assert_array_equal(scale_d.cpu().numpy(), scale_h)
     mins, maxs, cen, _ = rv.bbox_and_center(clouds[2].astype(np.float64))
     for views, levels in ((12, None), (5, None), (2, None), (7, [10.0, 89.99])):
         mine = rv.compute_camera_poses(views, mins, maxs, cen, 2.0, 42, levels)
