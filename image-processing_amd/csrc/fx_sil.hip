@@ -24,7 +24,7 @@ constexpr int SIL_HALO = 3;         // three 3-tap passes
 constexpr int SIL_MAX_TROWS = 64;   // rows of a blur tile, halo included
 constexpr int SIL_MAX_SIDE = 512;
 constexpr int SIL_RUNS_LDS = 1024;  // run table kept in LDS up to this many runs
-constexpr int SIL_MAX_GRID = 1536;
+constexpr int SIL_MAX_GRID = 1024;  // mask kernel grid when the occupancy query fails
 
 // PIL's box blur for GaussianBlur(radius=1): three passes of a box of radius
 // 0.25, i.e. taps (fw, ww, fw) / 2^24 with ww = uint32(float32(2^24) /
@@ -907,11 +907,23 @@ extern "C" int fx_silhouette_batch_u8(const uint8_t *d_img, int64_t B, int H, in
     int64_t chunk = (int64_t)(1ll << 30) / px;
     chunk = chunk < 1 ? 1 : (chunk > 32768 ? 32768 : chunk);
     chunk = chunk > B ? B : chunk;
-    const int grid = (int)(chunk < SIL_MAX_GRID ? chunk : SIL_MAX_GRID);
     const int rows = H > resolution ? H : resolution;
     const int side = W > resolution ? W : resolution;
     const int wpr = (side + 31) / 32;
     const int run_cap = resolution * (resolution / 2 + 1);
+    const size_t mask_lds = (size_t)3 * rows * wpr * sizeof(uint32_t);
+    // The mask kernel's blocks loop over images: a grid larger than what the device holds at once
+    // would run its surplus blocks after the others, on a half-empty device.
+    int grid = SIL_MAX_GRID;
+    {
+        int dev = 0, cus = 0, per_cu = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sil_mask_kernel, FX_BLOCK, mask_lds) == hipSuccess &&
+            cus > 0 && per_cu > 0)
+            grid = cus * per_cu;
+        grid = grid > 4096 ? 4096 : grid;
+    }
 
     const size_t blur_bytes = sil_align((size_t)chunk * px);
     const size_t hist_bytes = sil_align((size_t)chunk * 256 * sizeof(uint32_t));
@@ -955,7 +967,6 @@ extern "C" int fx_silhouette_batch_u8(const uint8_t *d_img, int64_t B, int H, in
     }
     A.tr = tr;
     const size_t blur_lds = (size_t)(tr + 2 * SIL_HALO) * Wp + 256 * sizeof(uint32_t);
-    const size_t mask_lds = (size_t)3 * rows * wpr * sizeof(uint32_t);
     if (mask_lds > 48 * 1024)  // beyond the default limit of dynamic LDS; set per call: the current device may differ
         FX_HIP_CHECK(hipFuncSetAttribute((const void *)sil_mask_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)mask_lds));
@@ -973,7 +984,7 @@ extern "C" int fx_silhouette_batch_u8(const uint8_t *d_img, int64_t B, int H, in
         else
             hipLaunchKernelGGL(sil_blur_kernel<false>, bgrid, dim3(FX_BLOCK), blur_lds, stream, A);
         FX_HIP_CHECK(hipGetLastError());
-        const int g = (int)(nb < grid ? nb : grid);
+        const int g = (int)(nb < grid ? nb : grid);  // persistent blocks: as many as are resident at once
         {
             FxProfileScope prof(stream);  // the longer of the two kernels; the last chunk's launch is what stays
             hipLaunchKernelGGL(sil_mask_kernel, dim3(g), dim3(FX_BLOCK), mask_lds, stream, A);
