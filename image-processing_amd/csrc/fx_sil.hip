@@ -1274,7 +1274,17 @@ extern "C" int fx_gray_fit_batch_u8(const uint8_t *d_img, int64_t B, int H, int 
                "fx_gray_fit_batch_u8: pitch %lld / stride %lld too small for %dx%d", (long long)pitch,
                (long long)stride, H, W);
     FX_REQUIRE(bg_value >= 0 && bg_value <= 255, "fx_gray_fit_batch_u8: bg_value %d", bg_value);
-    const int grid = (int)(B < 1024 ? B : 1024);
+    // persistent blocks: as many as the device holds at once (surplus blocks would run afterwards, on a partly empty device)
+    int resident = 768;
+    {
+        int dev = 0, cus = 0, per_cu = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gray_fit_kernel, FX_BLOCK, 0) == hipSuccess && cus > 0 &&
+            per_cu > 0)
+            resident = cus * per_cu > 2048 ? 2048 : cus * per_cu;
+    }
+    const int grid = (int)(B < resident ? B : resident);
     uint8_t *temp = (uint8_t *)fx_scratch((size_t)grid * SIL_MAX_SIDE * SIL_MAX_SIDE, 4);
     if (!temp)
         return FX_ENOMEM;
