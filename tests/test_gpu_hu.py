@@ -57,6 +57,24 @@ def test_gray_images_and_thresholds(gpu, c_oracle, thresh, on):
     check_against_oracle(run_gpu(gpu, imgs, thresh, on), c_oracle.hu_batch(imgs, thresh, on))
 
 
+@pytest.mark.parametrize("shape,thresh", [((37, 53), 127), ((64, 256), -1), ((224, 224), 127), ((130, 512), 100)])
+def test_many_small_images(gpu, c_oracle, shape, thresh):
+    """Batches of more than 8192 small images (several rounds of blocks per CU)."""
+    import torch
+    eng = pkg("engine")
+    H, W = shape
+    B = 8192 + 3
+    if H >= 8 and W >= 8 and thresh >= 0:
+        d = eng.synth_shapes(B, H, W, seed=11, device=gpu)
+    else:
+        g = torch.Generator(device=gpu)
+        g.manual_seed(5)
+        d = torch.randint(0, 256, (B, H, W), generator=g, device=gpu, dtype=torch.uint8)
+    res = eng.hu_batch(d, thresh=thresh, moments=True, hu=True)
+    got = {k: res[k].cpu().numpy() for k in ("moments24", "hu7", "hulog7")}
+    check_against_oracle(got, c_oracle.hu_batch(d.cpu().numpy(), thresh=thresh))
+
+
 def test_reference_silhouette_panels(gpu, c_oracle, hu_panels):
     """The 21 cleaned silhouettes the reference's production run computed Hu on."""
     check_against_oracle(run_gpu(gpu, hu_panels["masks"]), c_oracle.hu_batch(hu_panels["masks"]))
