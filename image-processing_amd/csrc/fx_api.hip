@@ -1,6 +1,8 @@
 // libfx: library state, error text, per-device scratch, launch timing.
 #include "fx_common.h"
 
+#include <map>
+#include <memory>
 #include <mutex>
 #include <string.h>
 
@@ -11,17 +13,32 @@ constexpr int kScratchSlots = 7;
 
 thread_local char g_err[512] = "";
 
-struct DeviceState {
+// Scratch is owned per (device, stream): work that two streams enqueue never
+// shares a buffer, and work on one stream is ordered by the stream itself.
+struct StreamState {
+    std::mutex call_mu;  // held by an entry point from its first scratch request until it returns
     void *scratch[kScratchSlots] = {};
     size_t scratch_bytes[kScratchSlots] = {};
 };
 
 std::mutex g_mu;
-DeviceState g_dev[kMaxDevices];
+std::map<std::pair<int, hipStream_t>, std::unique_ptr<StreamState>> g_streams;
 
 bool g_profile = false;
 thread_local hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
 thread_local bool g_ev_valid = false;
+
+StreamState *stream_state(hipStream_t stream)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices)
+        return nullptr;
+    std::lock_guard<std::mutex> lk(g_mu);
+    std::unique_ptr<StreamState> &st = g_streams[std::make_pair(dev, stream)];
+    if (!st)
+        st.reset(new StreamState());
+    return st.get();
+}
 
 }  // namespace
 
@@ -33,32 +50,39 @@ void fx_set_error(const char *fmt, ...)
     va_end(ap);
 }
 
-void *fx_scratch(size_t bytes, int slot)
+FxCallGuard::FxCallGuard(hipStream_t s) : stream(s), state(stream_state(s))
 {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices || slot < 0 ||
-        slot >= kScratchSlots) {
-        fx_set_error("fx_scratch: no current device");
+    if (state)
+        static_cast<StreamState *>(state)->call_mu.lock();
+}
+
+FxCallGuard::~FxCallGuard()
+{
+    if (state)
+        static_cast<StreamState *>(state)->call_mu.unlock();
+}
+
+void *FxCallGuard::scratch(size_t bytes, int slot)
+{
+    if (!state || slot < 0 || slot >= kScratchSlots) {
+        fx_set_error("fx scratch: no current device");
         return nullptr;
     }
-    std::lock_guard<std::mutex> lk(g_mu);
-    DeviceState &st = g_dev[dev];
+    StreamState &st = *static_cast<StreamState *>(state);
     if (st.scratch_bytes[slot] >= bytes && st.scratch[slot])
         return st.scratch[slot];
-    if (st.scratch[slot]) {
-        // The old block may still be in use by work already enqueued.
-        (void)hipDeviceSynchronize();
-        (void)hipFree(st.scratch[slot]);
-        st.scratch[slot] = nullptr;
-        st.scratch_bytes[slot] = 0;
-    }
+    // Stream-ordered growth: the new block exists from this point of the stream
+    // on, the old one is released once the work already enqueued has passed.
+    // Neither call waits for the device.
     size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
     void *p = nullptr;
-    hipError_t e = hipMalloc(&p, want);
+    hipError_t e = hipMallocAsync(&p, want, stream);
     if (e != hipSuccess) {
-        fx_set_error("fx_scratch: hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        fx_set_error("fx scratch: hipMallocAsync(%zu) failed: %s", want, hipGetErrorString(e));
         return nullptr;
     }
+    if (st.scratch[slot])
+        (void)hipFreeAsync(st.scratch[slot], stream);
     st.scratch[slot] = p;
     st.scratch_bytes[slot] = want;
     return p;
@@ -115,18 +139,39 @@ int fx_shutdown(void)
     std::lock_guard<std::mutex> lk(g_mu);
     int cur = 0;
     (void)hipGetDevice(&cur);
-    for (int d = 0; d < kMaxDevices; d++) {
+    for (auto &kv : g_streams) {
+        StreamState &st = *kv.second;
+        std::lock_guard<std::mutex> call(st.call_mu);
+        bool synced = false;
         for (int s = 0; s < kScratchSlots; s++) {
-            if (g_dev[d].scratch[s]) {
-                (void)hipSetDevice(d);
+            if (!st.scratch[s])
+                continue;
+            if (!synced) {
+                (void)hipSetDevice(kv.first.first);
                 (void)hipDeviceSynchronize();
-                (void)hipFree(g_dev[d].scratch[s]);
-                g_dev[d].scratch[s] = nullptr;
-                g_dev[d].scratch_bytes[s] = 0;
+                synced = true;
             }
+            (void)hipFree(st.scratch[s]);
+            st.scratch[s] = nullptr;
+            st.scratch_bytes[s] = 0;
         }
     }
     (void)hipSetDevice(cur);
+    return FX_OK;
+}
+
+int fx_release_stream(void *stream)
+{
+    StreamState *st = stream_state((hipStream_t)stream);
+    if (!st)
+        return FX_OK;
+    std::lock_guard<std::mutex> call(st->call_mu);
+    for (int s = 0; s < kScratchSlots; s++) {
+        if (st->scratch[s])
+            FX_HIP_CHECK(hipFreeAsync(st->scratch[s], (hipStream_t)stream));
+        st->scratch[s] = nullptr;
+        st->scratch_bytes[s] = 0;
+    }
     return FX_OK;
 }
 

@@ -382,7 +382,8 @@ extern "C" int fx_column_thresholds_f64(const double *d_x, int64_t rows, int col
     FX_REQUIRE(method >= 0 && method <= 2, "fx_column_thresholds_f64: method %d (0 median, 1 quantile, 2 otsu)", method);
     FX_REQUIRE(method != 1 || (q >= 0.0 && q <= 1.0), "fx_column_thresholds_f64: quantile %g outside [0, 1]", q);
     hipStream_t s = (hipStream_t)stream;
-    unsigned char *base = (unsigned char *)fx_scratch(BIN_GROUP * sizeof(BinCol) + BIN_Q * BIN_DIGITS * 4, 6);
+    FxCallGuard guard(s);
+    unsigned char *base = (unsigned char *)guard.scratch(BIN_GROUP * sizeof(BinCol) + BIN_Q * BIN_DIGITS * 4, 6);
     if (!base)
         return FX_ENOMEM;
     BinArgs A;

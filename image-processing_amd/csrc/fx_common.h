@@ -14,9 +14,23 @@
 
 // ---------------------------------------------------------------- host side
 void fx_set_error(const char *fmt, ...);
-// Per-device scratch owned by the library; grows, never shrinks until
-// fx_shutdown.  Returns NULL (and sets the error text) on failure.
-void *fx_scratch(size_t bytes, int slot);
+// An entry point that needs scratch creates one guard for the stream it
+// enqueues on and keeps it until it returns.  Scratch belongs to (device,
+// stream, slot): calls on different streams never share a buffer and may
+// overlap; calls on one stream reuse the buffer in stream order.  The guard
+// also serialises host threads that enqueue on the same stream.  A buffer
+// grows with the stream-ordered allocator (no device-wide wait) and is
+// released by fx_release_stream / fx_shutdown.
+struct FxCallGuard {
+    hipStream_t stream;
+    void *state;
+    explicit FxCallGuard(hipStream_t s);
+    ~FxCallGuard();
+    FxCallGuard(const FxCallGuard &) = delete;
+    FxCallGuard &operator=(const FxCallGuard &) = delete;
+    // NULL (and the error text set) on failure
+    void *scratch(size_t bytes, int slot);
+};
 
 struct FxProfileScope {
     hipStream_t stream;

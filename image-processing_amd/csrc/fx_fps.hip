@@ -314,7 +314,8 @@ extern "C" int fx_center_scale(const void *d_pts, int wide, const int64_t *h_off
     const size_t off_bytes = fps_align((size_t)(B + 1) * sizeof(int64_t));
     const size_t cen_bytes = fps_align((size_t)B * 3 * sizeof(double));
     const size_t max_bytes = fps_align((size_t)B * sizeof(unsigned long long));
-    unsigned char *base = (unsigned char *)fx_scratch(off_bytes + cen_bytes + max_bytes, 5);
+    FxCallGuard guard((hipStream_t)stream);
+    unsigned char *base = (unsigned char *)guard.scratch(off_bytes + cen_bytes + max_bytes, 5);
     if (!base)
         return FX_ENOMEM;
     CloudArgs A;
@@ -373,7 +374,8 @@ extern "C" int fx_fps_f32(const float *d_pts, const int64_t *h_offsets, int64_t 
     const size_t start_bytes = fps_align((size_t)B * sizeof(int64_t));
     const size_t ids_bytes = fps_align((size_t)B * sizeof(int32_t));
     const size_t dist_bytes = cls[5].empty() ? 0 : fps_align((size_t)total * sizeof(double));
-    unsigned char *base = (unsigned char *)fx_scratch(off_bytes + start_bytes + ids_bytes + dist_bytes, 5);
+    FxCallGuard guard((hipStream_t)stream);
+    unsigned char *base = (unsigned char *)guard.scratch(off_bytes + start_bytes + ids_bytes + dist_bytes, 5);
     if (!base)
         return FX_ENOMEM;
     std::vector<int32_t> ids;

@@ -1391,6 +1391,7 @@ extern "C" int fx_hu_batch_u8(const uint8_t *d_img, int64_t B, int H, int W, int
     FX_REQUIRE(B <= 0x7fffffffLL, "fx_hu_batch_u8: B too large for one launch");
 
     hipStream_t s = (hipStream_t)stream;
+    FxCallGuard guard(s);
     HuArgs A;
     A.img = d_img;
     A.B = B;
@@ -1428,11 +1429,8 @@ extern "C" int fx_hu_batch_u8(const uint8_t *d_img, int64_t B, int H, int W, int
     //          position (row, chunk) in 10 + 6 bits;
     //   mask   contour descriptor of images up to 2048 x 2048 whose bit mask fits in LDS;
     //   tiled  anything larger, Hu only: band kernel per 1024 x 256 tile + 128-bit combine.
-    bool band = A.cpr <= FX_WAVE && H <= 1024;
-    const char *force = getenv("FX_HU_KERNEL");  // "mask": development switch
+    const bool band = A.cpr <= FX_WAVE && H <= 1024;
     const bool mask_ok = W <= 2048 && H <= 2048 && mask_bytes <= 128 * 1024;
-    if (force && strcmp(force, "mask") == 0 && mask_ok)
-        band = false;
 
     if (!band && contour) {
         if (!mask_ok) {
@@ -1441,10 +1439,6 @@ extern "C" int fx_hu_batch_u8(const uint8_t *d_img, int64_t B, int H, int W, int
             return FX_EINVAL;
         }
         FxProfileScope prof(s);  // launch timing (when switched on) brackets the streaming kernel only
-        return launch_mask(A, mode, contour, aligned, mask_lds, s);
-    }
-    if (!band && force && strcmp(force, "mask") == 0 && mask_ok) {
-        FxProfileScope prof(s);
         return launch_mask(A, mode, contour, aligned, mask_lds, s);
     }
 
@@ -1461,7 +1455,7 @@ extern "C" int fx_hu_batch_u8(const uint8_t *d_img, int64_t B, int H, int W, int
         A.qcap = 0;
         A.wave_lds = BAND_SLAB_BYTES;
         BandScratch G;
-        G.sums = (u64 *)fx_scratch((size_t)blocks * BAND_SUMS * sizeof(u64), 1);
+        G.sums = (u64 *)guard.scratch((size_t)blocks * BAND_SUMS * sizeof(u64), 1);
         if (!G.sums)
             return FX_ENOMEM;
         G.qcount = nullptr;
@@ -1491,7 +1485,7 @@ extern "C" int fx_hu_batch_u8(const uint8_t *d_img, int64_t B, int H, int W, int
     const size_t sums_bytes = (size_t)B * BAND_SUMS * sizeof(u64);
     const size_t count_bytes = (size_t)B * FX_WAVES_PER_BLOCK * 4;
     const size_t redo_bytes = contour ? 16 + (((size_t)B * 4 + 15) & ~(size_t)15) : 0;
-    unsigned char *base = (unsigned char *)fx_scratch(sums_bytes + count_bytes + redo_bytes, 1);
+    unsigned char *base = (unsigned char *)guard.scratch(sums_bytes + count_bytes + redo_bytes, 1);
     if (!base)
         return FX_ENOMEM;
     BandScratch G;
@@ -1566,6 +1560,7 @@ extern "C" int fx_hu_partial_u8(const uint8_t *d_img, int64_t B, int H, int W, i
     FX_REQUIRE(thresh < 255, "fx_hu_partial_u8: thresh %d must be < 255 (or negative)", thresh);
     FX_REQUIRE(thresh < 0 || (on_value >= 1 && on_value <= 255), "fx_hu_partial_u8: on_value %d outside 1..255", on_value);
     hipStream_t s = (hipStream_t)stream;
+    FxCallGuard guard(s);
     HuArgs A = {};
     A.img = d_img;
     A.B = B;
@@ -1591,7 +1586,7 @@ extern "C" int fx_hu_partial_u8(const uint8_t *d_img, int64_t B, int H, int W, i
     A.qcap = 0;
     A.wave_lds = BAND_SLAB_BYTES;
     BandScratch G = {};
-    G.sums = (u64 *)fx_scratch((size_t)blocks * BAND_SUMS * sizeof(u64), 1);
+    G.sums = (u64 *)guard.scratch((size_t)blocks * BAND_SUMS * sizeof(u64), 1);
     if (!G.sums)
         return FX_ENOMEM;
     int rc;

@@ -907,8 +907,10 @@ int launch_small_sets(const PcaArgs &A, int64_t max_points, hipStream_t s)
 
 // Builds the chunk lists for the given large clouds (set index + point count,
 // host arrays) and runs the passes.
-int launch_large_clouds(const PcaArgs &A, const int32_t *h_sets, const int64_t *h_sizes, int64_t n_clouds, hipStream_t s)
+int launch_large_clouds(const PcaArgs &A, const int32_t *h_sets, const int64_t *h_sizes, int64_t n_clouds,
+                        FxCallGuard &guard)
 {
+    hipStream_t s = guard.stream;
     int64_t n_chunks = 0;
     for (int64_t k = 0; k < n_clouds; k++)
         n_chunks += (h_sizes[k] + CLOUD_CHUNK - 1) / CLOUD_CHUNK;
@@ -934,7 +936,7 @@ int launch_large_clouds(const PcaArgs &A, const int32_t *h_sets, const int64_t *
     const size_t part_bytes = (size_t)n_chunks * PART * sizeof(double);
     const size_t hist_bytes = (size_t)n_chunks * HIST_MAX * sizeof(uint32_t);
     const size_t state_bytes = (size_t)n_clouds * STATE * sizeof(double);
-    unsigned char *base = (unsigned char *)fx_scratch(list_bytes + part_bytes + hist_bytes + state_bytes, 2);
+    unsigned char *base = (unsigned char *)guard.scratch(list_bytes + part_bytes + hist_bytes + state_bytes, 2);
     if (!base) {
         free(h);
         return FX_ENOMEM;
@@ -995,11 +997,11 @@ extern "C" int fx_pca_batch_f32(const float *d_pts, const int64_t *d_offsets, in
     A.out = d_out;
     A.eig = d_eig;
     A.slab_floats = 0;
+    FxCallGuard guard(s);
 
     if (!d_offsets) {
         FxProfileScope prof(s);
-        const char *force = getenv("FX_PCA_KERNEL");  // "lds": development switch
-        const bool reg_ok = dims == 3 && N >= 3 && N <= REG_SET_MAX_POINTS && !(force && strcmp(force, "lds") == 0);
+        const bool reg_ok = dims == 3 && N >= 3 && N <= REG_SET_MAX_POINTS;
         if (reg_ok)
             return launch_reg_sets(A, N, N % 4 != 0 || (uintptr_t)d_pts % 16 != 0, s);
         if (N <= WAVE_SET_MAX_POINTS)
@@ -1016,7 +1018,7 @@ extern "C" int fx_pca_batch_f32(const float *d_pts, const int64_t *d_offsets, in
             sets[b] = (int32_t)b;
             sizes[b] = N;
         }
-        const int rc = launch_large_clouds(A, sets, sizes, B, s);
+        const int rc = launch_large_clouds(A, sets, sizes, B, guard);
         free(sets);
         free(sizes);
         return rc;
@@ -1051,8 +1053,7 @@ extern "C" int fx_pca_batch_f32(const float *d_pts, const int64_t *d_offsets, in
         return FX_ENOMEM;
     }
     // work list: sets for the register kernel, then those for the LDS kernel, then the large clouds
-    const char *force = getenv("FX_PCA_KERNEL");
-    const int64_t reg_max = dims == 3 && !(force && strcmp(force, "lds") == 0) ? REG_SET_MAX_POINTS : -1;
+    const int64_t reg_max = dims == 3 ? REG_SET_MAX_POINTS : -1;
     int64_t n_reg = 0, n_small = 0, n_large = 0, max_reg = 3, max_small = 3;
     bool ok = true;
     for (int64_t b = 0; b < B; b++) {
@@ -1088,7 +1089,7 @@ extern "C" int fx_pca_batch_f32(const float *d_pts, const int64_t *d_offsets, in
     }
     int32_t *d_ids = nullptr;
     if (n_small > 0) {
-        d_ids = (int32_t *)fx_scratch((size_t)n_small * sizeof(int32_t), 0);
+        d_ids = (int32_t *)guard.scratch((size_t)n_small * sizeof(int32_t), 0);
         if (!d_ids) {
             free(h_ids);
             free(h_large_sizes);
@@ -1120,7 +1121,7 @@ extern "C" int fx_pca_batch_f32(const float *d_pts, const int64_t *d_offsets, in
         rc = launch_small_sets(S, max_small, s);
     }
     if (rc == FX_OK && n_large > 0)
-        rc = launch_large_clouds(A, h_ids + n_small, h_large_sizes, n_large, s);
+        rc = launch_large_clouds(A, h_ids + n_small, h_large_sizes, n_large, guard);
     free(h_ids);
     free(h_large_sizes);
     return rc;

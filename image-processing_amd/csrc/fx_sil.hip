@@ -927,8 +927,10 @@ extern "C" int fx_silhouette_batch_u8(const uint8_t *d_img, int64_t B, int H, in
 
     const size_t blur_bytes = sil_align((size_t)chunk * px);
     const size_t hist_bytes = sil_align((size_t)chunk * 256 * sizeof(uint32_t));
-    const size_t runs_bytes = sil_align((size_t)grid * 2 * run_cap * sizeof(uint32_t));
-    unsigned char *base = (unsigned char *)fx_scratch(blur_bytes + hist_bytes + runs_bytes, 3);
+    const int64_t run_blocks = chunk < grid ? chunk : grid;  // blocks a launch really has
+    const size_t runs_bytes = sil_align((size_t)run_blocks * 2 * run_cap * sizeof(uint32_t));
+    FxCallGuard guard(stream);
+    unsigned char *base = (unsigned char *)guard.scratch(blur_bytes + hist_bytes + runs_bytes, 3);
     if (!base)
         return FX_ENOMEM;
 
@@ -1285,7 +1287,8 @@ extern "C" int fx_gray_fit_batch_u8(const uint8_t *d_img, int64_t B, int H, int 
             resident = cus * per_cu > 2048 ? 2048 : cus * per_cu;
     }
     const int grid = (int)(B < resident ? B : resident);
-    uint8_t *temp = (uint8_t *)fx_scratch((size_t)grid * SIL_MAX_SIDE * SIL_MAX_SIDE, 4);
+    FxCallGuard guard((hipStream_t)stream_);
+    uint8_t *temp = (uint8_t *)guard.scratch((size_t)grid * SIL_MAX_SIDE * SIL_MAX_SIDE, 4);
     if (!temp)
         return FX_ENOMEM;
     FitArgs A;

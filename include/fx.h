@@ -18,7 +18,12 @@
  *     default stream) and the call returns without waiting for it;
  *   - no C++ exception crosses this boundary;
  *   - scratch memory that an entry point needs beyond its arguments is owned
- *     by the library, per device, and released by fx_shutdown.
+ *     by the library per (device, stream): calls on different streams never
+ *     share a buffer and may overlap freely; calls on one stream reuse it in
+ *     stream order.  A buffer grows with the stream-ordered allocator
+ *     (hipMallocAsync / hipFreeAsync on `stream`), so no entry point waits for
+ *     the device unless its comment says so.  fx_release_stream returns a
+ *     stream's buffers, fx_shutdown all of them.
  */
 #ifndef FX_H
 #define FX_H
@@ -45,8 +50,12 @@ extern "C" {
  * reference function.  Safe to call more than once. */
 int fx_init(int device);
 
-/* Releases every per-device scratch buffer the library holds. */
+/* Releases every scratch buffer the library holds (waits for the devices). */
 int fx_shutdown(void);
+
+/* Returns the scratch buffers bound to `stream` on the current device, in
+ * stream order (call it before destroying a stream the library has seen). */
+int fx_release_stream(void *stream);
 
 /* Message of the most recent failing call on this thread ("" if none). */
 const char *fx_last_error(void);

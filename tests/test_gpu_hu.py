@@ -246,3 +246,37 @@ def test_row_bands_equal_whole_image(gpu, oracle):
             assert [fxd.from_limbs(host[k]) for k in range(10)] == [int(v) for v in raw]
     out = fxd.hu_rowbands(img, 0, thresh, on_value, moments=True)       # single process: no group, one band
     assert torch.equal(out["moments24"], whole["moments24"])
+
+
+def test_two_streams_overlap(gpu, c_oracle):
+    """Scratch belongs to (device, stream): calls enqueued on two streams with
+    different batch sizes run concurrently and neither disturbs the other."""
+    eng = pkg("engine")
+    a = eng.synth_shapes(6000, 512, 512, seed=31, device=gpu)
+    b = eng.synth_shapes(777, 256, 256, seed=32, device=gpu)
+    c = eng.synth_shapes(9, 224, 224, seed=33, device=gpu)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(device=gpu), torch.cuda.Stream(device=gpu)
+    res = {}
+    for rnd in range(3):   # the buffers grow on the first round and are reused afterwards
+        with torch.cuda.stream(s1):
+            res["a"] = eng.hu_batch(a, thresh=127, moments=True, hu=True, contour_bins=8)
+        with torch.cuda.stream(s2):
+            res["b"] = eng.hu_batch(b, thresh=127, moments=True, hu=True, contour_bins=8)
+            res["c"] = eng.hu_batch(c, thresh=127, moments=True, hu=True)
+        with torch.cuda.stream(s1):
+            res["c1"] = eng.hu_batch(c, thresh=127, moments=True, hu=True)   # smaller batch after the big one
+    torch.cuda.synchronize()
+    single = {"a": eng.hu_batch(a, thresh=127, moments=True, hu=True, contour_bins=8),
+              "b": eng.hu_batch(b, thresh=127, moments=True, hu=True, contour_bins=8)}
+    torch.cuda.synchronize()
+    for k in ("a", "b"):
+        for f in ("moments24", "hu7", "hulog7", "cpca"):
+            np.testing.assert_array_equal(res[k][f].cpu().numpy(), single[k][f].cpu().numpy(), err_msg=f"{k}.{f}")
+    for k, src in (("a", a[-200:]), ("b", b[:200]), ("c", c), ("c1", c)):
+        got = {f: res[k][f][-200:].cpu().numpy() if k == "a" else res[k][f][:200].cpu().numpy()
+               for f in ("moments24", "hu7", "hulog7")}
+        check_against_oracle(got, c_oracle.hu_batch(src.cpu().numpy(), thresh=127))
+    pkg("_lib").call("fx_release_stream", int(s1.cuda_stream))
+    pkg("_lib").call("fx_release_stream", int(s2.cuda_stream))
+    torch.cuda.synchronize()
