@@ -27,6 +27,8 @@ SIGNATURES = {
     "fx_abi_version": (c_int, []),
     "fx_hu_batch_u8": (c_int, [c_void_p, c_i64, c_int, c_int, c_i64, c_i64, c_int, c_int,
                                c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "fx_hu_batch_u8_noalloc": (c_int, [c_void_p, c_i64, c_int, c_int, c_i64, c_i64, c_int, c_int,
+                                       c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "fx_release_stream": (c_int, [c_void_p]),
     "fx_hu_partial_u8": (c_int, [c_void_p, c_i64, c_int, c_int, c_i64, c_i64, c_int, c_int, c_i64, c_void_p, c_void_p]),
     "fx_hu_from_partial": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p]),

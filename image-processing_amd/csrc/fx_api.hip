@@ -131,7 +131,7 @@ int fx_init(int device)
                      prop.gcnArchName);
         return FX_ENODEV;
     }
-    return FX_OK;
+    return fx_hu_noalloc_setup();
 }
 
 int fx_shutdown(void)

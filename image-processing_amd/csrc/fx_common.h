@@ -32,6 +32,10 @@ struct FxCallGuard {
     void *scratch(size_t bytes, int slot);
 };
 
+// Defined beside the block it looks up (fx_hu.hip); fx_init calls it so that
+// fx_hu_batch_u8_noalloc finds the address ready.
+int fx_hu_noalloc_setup(void);
+
 struct FxProfileScope {
     hipStream_t stream;
     bool active;

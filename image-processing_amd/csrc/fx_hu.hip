@@ -13,6 +13,7 @@
 // wave shuffles + LDS for the block reduction.  No MFMA.
 #include "fx_common.h"
 #include "fx_eig.h"
+#include <mutex>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1368,6 +1369,33 @@ int launch_mask(const HuArgs &A, int mode, bool contour, bool aligned, size_t ld
                                : launch_image_kernel<MODE_THRESH, false>(A, aligned, lds, s);
 }
 
+// Where an entry point's scratch comes from: the library's per-stream buffer
+// (grown on demand) or a fixed block that is never (re)allocated.
+struct HuScratch {
+    FxCallGuard *guard;     // per-stream buffer, or
+    unsigned char *fixed;   // a block of fixed_bytes bytes
+    size_t fixed_bytes;
+    const char *who;
+    // `units` = images (or tiles) the launch keeps a record for
+    unsigned char *get(size_t bytes, int64_t units) const
+    {
+        if (guard)
+            return (unsigned char *)guard->scratch(bytes, 1);
+        if (units > FX_HU_NOALLOC_MAX_IMAGES || bytes > fixed_bytes) {
+            fx_set_error("%s: this batch needs records for %lld images or tiles (%zu bytes); the built-in block holds "
+                         "%d (%zu bytes): at most %d images up to 1024 x 1024, or %d tiles of 1024 x 256 of larger "
+                         "ones, per call", who, (long long)units, bytes, FX_HU_NOALLOC_MAX_IMAGES, fixed_bytes,
+                         FX_HU_NOALLOC_MAX_IMAGES, FX_HU_NOALLOC_MAX_IMAGES);
+            return nullptr;
+        }
+        return fixed;
+    }
+};
+
+int hu_batch_impl(const char *who, const HuScratch &scratch, const uint8_t *d_img, int64_t B, int H, int W,
+                  int64_t pitch_bytes, int64_t img_stride_bytes, int thresh, int on_value, double *d_moments24,
+                  double *d_hu7, float *d_hulog7, int n_bins, float *d_cpca, double *d_ceig, hipStream_t s);
+
 }  // namespace
 
 extern "C" int fx_hu_batch_u8(const uint8_t *d_img, int64_t B, int H, int W, int64_t pitch_bytes,
@@ -1378,20 +1406,33 @@ extern "C" int fx_hu_batch_u8(const uint8_t *d_img, int64_t B, int H, int W, int
     FX_REQUIRE(B >= 0, "fx_hu_batch_u8: B = %lld", (long long)B);
     if (B == 0)
         return FX_OK;
-    FX_REQUIRE(d_img != nullptr, "fx_hu_batch_u8: d_img is NULL");
-    FX_REQUIRE(H >= 1 && W >= 1 && H <= 16384 && W <= 16384, "fx_hu_batch_u8: image %d x %d outside 1..16384", H, W);
-    FX_REQUIRE(pitch_bytes >= W, "fx_hu_batch_u8: pitch %lld < width %d", (long long)pitch_bytes, W);
-    FX_REQUIRE(B == 1 || img_stride_bytes >= pitch_bytes * (int64_t)(H - 1) + W,
-               "fx_hu_batch_u8: image stride %lld overlaps images", (long long)img_stride_bytes);
-    FX_REQUIRE(thresh < 255, "fx_hu_batch_u8: thresh %d must be < 255 (or negative)", thresh);
-    FX_REQUIRE(thresh < 0 || (on_value >= 1 && on_value <= 255), "fx_hu_batch_u8: on_value %d outside 1..255", on_value);
-    FX_REQUIRE(d_moments24 || d_hu7 || d_hulog7 || d_cpca, "fx_hu_batch_u8: no output requested");
-    FX_REQUIRE(!d_cpca || (n_bins >= 1 && n_bins <= 64), "fx_hu_batch_u8: n_bins %d outside 1..64", n_bins);
-    FX_REQUIRE(d_cpca || !d_ceig, "fx_hu_batch_u8: d_ceig needs d_cpca");
-    FX_REQUIRE(B <= 0x7fffffffLL, "fx_hu_batch_u8: B too large for one launch");
+    FxCallGuard guard((hipStream_t)stream);
+    const HuScratch scratch = {&guard, nullptr, 0, "fx_hu_batch_u8"};
+    return hu_batch_impl("fx_hu_batch_u8", scratch, d_img, B, H, W, pitch_bytes, img_stride_bytes, thresh, on_value,
+                         d_moments24, d_hu7, d_hulog7, n_bins, d_cpca, d_ceig, (hipStream_t)stream);
+}
 
-    hipStream_t s = (hipStream_t)stream;
-    FxCallGuard guard(s);
+namespace {
+
+int hu_batch_impl(const char *who, const HuScratch &scratch, const uint8_t *d_img, int64_t B, int H, int W,
+                  int64_t pitch_bytes, int64_t img_stride_bytes, int thresh, int on_value, double *d_moments24,
+                  double *d_hu7, float *d_hulog7, int n_bins, float *d_cpca, double *d_ceig, hipStream_t s)
+{
+    FX_REQUIRE(B >= 0, "%s: B = %lld", who, (long long)B);
+    if (B == 0)
+        return FX_OK;
+    FX_REQUIRE(d_img != nullptr, "%s: d_img is NULL", who);
+    FX_REQUIRE(H >= 1 && W >= 1 && H <= 16384 && W <= 16384, "%s: image %d x %d outside 1..16384", who, H, W);
+    FX_REQUIRE(pitch_bytes >= W, "%s: pitch %lld < width %d", who, (long long)pitch_bytes, W);
+    FX_REQUIRE(B == 1 || img_stride_bytes >= pitch_bytes * (int64_t)(H - 1) + W,
+               "%s: image stride %lld overlaps images", who, (long long)img_stride_bytes);
+    FX_REQUIRE(thresh < 255, "%s: thresh %d must be < 255 (or negative)", who, thresh);
+    FX_REQUIRE(thresh < 0 || (on_value >= 1 && on_value <= 255), "%s: on_value %d outside 1..255", who, on_value);
+    FX_REQUIRE(d_moments24 || d_hu7 || d_hulog7 || d_cpca, "%s: no output requested", who);
+    FX_REQUIRE(!d_cpca || (n_bins >= 1 && n_bins <= 64), "%s: n_bins %d outside 1..64", who, n_bins);
+    FX_REQUIRE(d_cpca || !d_ceig, "%s: d_ceig needs d_cpca", who);
+    FX_REQUIRE(B <= 0x7fffffffLL, "%s: B too large for one launch", who);
+
     HuArgs A;
     A.img = d_img;
     A.B = B;
@@ -1434,8 +1475,8 @@ extern "C" int fx_hu_batch_u8(const uint8_t *d_img, int64_t B, int H, int W, int
 
     if (!band && contour) {
         if (!mask_ok) {
-            fx_set_error("fx_hu_batch_u8: the contour descriptor supports images up to 2048 x 2048 with at most "
-                         "128 KiB of bit mask (got %d x %d); Hu moments alone have no such limit", H, W);
+            fx_set_error("%s: the contour descriptor supports images up to 2048 x 2048 with at most "
+                         "128 KiB of bit mask (got %d x %d); Hu moments alone have no such limit", who, H, W);
             return FX_EINVAL;
         }
         FxProfileScope prof(s);  // launch timing (when switched on) brackets the streaming kernel only
@@ -1447,7 +1488,7 @@ extern "C" int fx_hu_batch_u8(const uint8_t *d_img, int64_t B, int H, int W, int
         A.tiles_x = (W + TILE_W - 1) / TILE_W;
         A.tiles_y = (H + TILE_H - 1) / TILE_H;
         const int64_t blocks = B * A.tiles_x * A.tiles_y;
-        FX_REQUIRE(blocks <= 0x7fffffffLL, "fx_hu_batch_u8: too many tiles for one launch");
+        FX_REQUIRE(blocks <= 0x7fffffffLL, "%s: too many tiles for one launch", who);
         A.cpr = FX_WAVE;
         A.bpw = 1;
         A.nbands = FX_WAVES_PER_BLOCK;
@@ -1455,9 +1496,9 @@ extern "C" int fx_hu_batch_u8(const uint8_t *d_img, int64_t B, int H, int W, int
         A.qcap = 0;
         A.wave_lds = BAND_SLAB_BYTES;
         BandScratch G;
-        G.sums = (u64 *)guard.scratch((size_t)blocks * BAND_SUMS * sizeof(u64), 1);
+        G.sums = (u64 *)scratch.get((size_t)blocks * BAND_SUMS * sizeof(u64), blocks);
         if (!G.sums)
-            return FX_ENOMEM;
+            return scratch.guard ? FX_ENOMEM : FX_EINVAL;
         G.qcount = nullptr;
         G.redo_count = nullptr;
         G.redo_list = nullptr;
@@ -1485,9 +1526,9 @@ extern "C" int fx_hu_batch_u8(const uint8_t *d_img, int64_t B, int H, int W, int
     const size_t sums_bytes = (size_t)B * BAND_SUMS * sizeof(u64);
     const size_t count_bytes = (size_t)B * FX_WAVES_PER_BLOCK * 4;
     const size_t redo_bytes = contour ? 16 + (((size_t)B * 4 + 15) & ~(size_t)15) : 0;
-    unsigned char *base = (unsigned char *)guard.scratch(sums_bytes + count_bytes + redo_bytes, 1);
+    unsigned char *base = scratch.get(sums_bytes + count_bytes + redo_bytes, B);
     if (!base)
-        return FX_ENOMEM;
+        return scratch.guard ? FX_ENOMEM : FX_EINVAL;
     BandScratch G;
     G.sums = (u64 *)base;
     G.qcount = (uint32_t *)(base + sums_bytes);
@@ -1528,6 +1569,57 @@ extern "C" int fx_hu_batch_u8(const uint8_t *d_img, int64_t B, int H, int W, int
     return FX_OK;
 }
 
+// The block behind fx_hu_batch_u8_noalloc: part of the code object, so every
+// device the library runs on holds its own copy at its own address from the
+// moment the module is loaded until the process ends.  Host code only ever
+// uses the per-device address that hipGetSymbolAddress returns.
+constexpr size_t HU_NOALLOC_BYTES =
+    (size_t)FX_HU_NOALLOC_MAX_IMAGES * (BAND_SUMS * sizeof(u64) + FX_WAVES_PER_BLOCK * 4 + 4) + 256;
+static __device__ __align__(256) unsigned char g_hu_noalloc_scratch[HU_NOALLOC_BYTES];
+
+constexpr int HU_NOALLOC_MAX_DEVICES = 16;
+std::mutex g_hu_noalloc_mu;
+unsigned char *g_hu_noalloc_ptr[HU_NOALLOC_MAX_DEVICES] = {};
+
+}  // namespace
+
+// Looks up the current device's copy of the built-in block (once per device).
+int fx_hu_noalloc_setup(void)
+{
+    int dev = -1;
+    FX_HIP_CHECK(hipGetDevice(&dev));
+    FX_REQUIRE(dev >= 0 && dev < HU_NOALLOC_MAX_DEVICES, "fx_hu_batch_u8_noalloc: device %d out of range", dev);
+    std::lock_guard<std::mutex> lk(g_hu_noalloc_mu);
+    if (g_hu_noalloc_ptr[dev])
+        return FX_OK;
+    unsigned char *ptr = nullptr;
+    FX_HIP_CHECK(hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(g_hu_noalloc_scratch)));
+    FX_REQUIRE(ptr != nullptr, "fx_hu_batch_u8_noalloc: the built-in scratch block has no address on device %d", dev);
+    g_hu_noalloc_ptr[dev] = ptr;
+    return FX_OK;
+}
+
+extern "C" int fx_hu_batch_u8_noalloc(const uint8_t *d_img, int64_t B, int H, int W, int64_t pitch_bytes,
+                                      int64_t img_stride_bytes, int thresh, int on_value, double *d_moments24,
+                                      double *d_hu7, float *d_hulog7, int n_bins, float *d_cpca, double *d_ceig,
+                                      void *stream)
+{
+    FX_REQUIRE(B >= 0, "fx_hu_batch_u8_noalloc: B = %lld", (long long)B);
+    if (B == 0)
+        return FX_OK;
+    int dev = -1;
+    FX_HIP_CHECK(hipGetDevice(&dev));
+    FX_REQUIRE(dev >= 0 && dev < HU_NOALLOC_MAX_DEVICES, "fx_hu_batch_u8_noalloc: device %d out of range", dev);
+    if (!g_hu_noalloc_ptr[dev]) {
+        const int rc = fx_hu_noalloc_setup();
+        if (rc != FX_OK)
+            return rc;
+    }
+    const HuScratch scratch = {nullptr, g_hu_noalloc_ptr[dev], HU_NOALLOC_BYTES, "fx_hu_batch_u8_noalloc"};
+    return hu_batch_impl("fx_hu_batch_u8_noalloc", scratch, d_img, B, H, W, pitch_bytes, img_stride_bytes, thresh,
+                         on_value, d_moments24, d_hu7, d_hulog7, n_bins, d_cpca, d_ceig, (hipStream_t)stream);
+}
+
 extern "C" int fx_hu_groupstat(const float *d_hulog7, const int64_t *d_group_offsets, int64_t G, float *d_out14,
                                void *stream)
 {
@@ -1560,7 +1652,6 @@ extern "C" int fx_hu_partial_u8(const uint8_t *d_img, int64_t B, int H, int W, i
     FX_REQUIRE(thresh < 255, "fx_hu_partial_u8: thresh %d must be < 255 (or negative)", thresh);
     FX_REQUIRE(thresh < 0 || (on_value >= 1 && on_value <= 255), "fx_hu_partial_u8: on_value %d outside 1..255", on_value);
     hipStream_t s = (hipStream_t)stream;
-    FxCallGuard guard(s);
     HuArgs A = {};
     A.img = d_img;
     A.B = B;
@@ -1586,6 +1677,7 @@ extern "C" int fx_hu_partial_u8(const uint8_t *d_img, int64_t B, int H, int W, i
     A.qcap = 0;
     A.wave_lds = BAND_SLAB_BYTES;
     BandScratch G = {};
+    FxCallGuard guard(s);
     G.sums = (u64 *)guard.scratch((size_t)blocks * BAND_SUMS * sizeof(u64), 1);
     if (!G.sums)
         return FX_ENOMEM;

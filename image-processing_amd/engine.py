@@ -39,13 +39,20 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 def hu_batch(images: torch.Tensor, thresh: int = -1, on_value: int = 255, *, moments: bool = False,
-             hu: bool = False, contour_bins: Optional[int] = None, contour_eig: bool = False) -> dict:
+             hu: bool = False, contour_bins: Optional[int] = None, contour_eig: bool = False,
+             out: Optional[dict] = None, noalloc: bool = False) -> dict:
     """Log-Hu vectors of a batch of uint8 images [B, H, W] (rows may be padded:
     any strides with a unit inner stride are accepted).
 
     Returns {"hulog7": f32 [B,7]} plus, on request, "moments24" f64 [B,24]
     (the cv2.moments record), "hu7" f64 [B,7], "cpca" f32 [B, 9+contour_bins]
     (PCA descriptor of the contour pixels) and "ceig" f64 [B,6].
+
+    `out` supplies preallocated output tensors under those names (contiguous,
+    right shape and dtype); with noalloc=True the library entry point that
+    performs no device allocation is used (fx_hu_batch_u8_noalloc: scratch in a
+    built-in block, at most 65536 images per call, calls on one device must not
+    overlap).
     """
     _require_cuda(images, "images")
     if images.dtype != torch.uint8 or images.dim() != 3:
@@ -55,22 +62,30 @@ def hu_batch(images: torch.Tensor, thresh: int = -1, on_value: int = 255, *, mom
     stream = _enter(images.device)
     B, H, W = images.shape
     dev = images.device
-    out = {"hulog7": torch.empty((B, HU_COLS), dtype=torch.float32, device=dev)}
+    nb = int(contour_bins) if contour_bins is not None else 0
+    want = {"hulog7": ((B, HU_COLS), torch.float32)}
     if moments:
-        out["moments24"] = torch.empty((B, MOMENT_COLS), dtype=torch.float64, device=dev)
+        want["moments24"] = ((B, MOMENT_COLS), torch.float64)
     if hu:
-        out["hu7"] = torch.empty((B, HU_COLS), dtype=torch.float64, device=dev)
-    nb = 0
+        want["hu7"] = ((B, HU_COLS), torch.float64)
     if contour_bins is not None:
-        nb = int(contour_bins)
-        out["cpca"] = torch.empty((B, 9 + nb), dtype=torch.float32, device=dev)
+        want["cpca"] = ((B, 9 + nb), torch.float32)
         if contour_eig:
-            out["ceig"] = torch.empty((B, 6), dtype=torch.float64, device=dev)
+            want["ceig"] = ((B, 6), torch.float64)
+    if out is None:
+        out = {k: torch.empty(shape, dtype=dt, device=dev) for k, (shape, dt) in want.items()}
+    else:
+        for k, (shape, dt) in want.items():
+            t = out.get(k)
+            if t is None or tuple(t.shape) != shape or t.dtype != dt or t.device != dev or not t.is_contiguous():
+                raise ValueError(f"out[{k!r}] must be a contiguous {dt} tensor of shape {shape} on {dev}")
+        out = {k: out[k] for k in want}
     if B == 0:
         return out
     pitch = images.stride(1) if H > 1 else W
     stride = images.stride(0) if B > 1 else pitch * H
-    _lib.call("fx_hu_batch_u8", images.data_ptr(), B, H, W, pitch, stride, int(thresh), int(on_value),
+    _lib.call("fx_hu_batch_u8_noalloc" if noalloc else "fx_hu_batch_u8", images.data_ptr(), B, H, W, pitch, stride,
+              int(thresh), int(on_value),
               _ptr(out.get("moments24")), _ptr(out.get("hu7")), out["hulog7"].data_ptr(), nb,
               _ptr(out.get("cpca")), _ptr(out.get("ceig")), stream)
     return out

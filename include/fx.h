@@ -100,6 +100,27 @@ int fx_hu_batch_u8(const uint8_t *d_img, int64_t B, int H, int W,
                    void *stream);
 
 /*
+ * fx_hu_batch_u8 for callers that must not allocate: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  It has no
+ * counterpart in the reference.  Same arguments, same kernels and bit-identical
+ * results; the per-image sums, queue counters and redo list live in a block of
+ * FX_HU_NOALLOC_MAX_IMAGES * 148 + 256 bytes (about 9.3 MiB) that is part of
+ * the library's code object on every device, and the call makes no hipMalloc,
+ * hipFree or other allocating call.  Limit: B <= FX_HU_NOALLOC_MAX_IMAGES for
+ * images up to 1024 x 1024, B * ceil(W / 1024) * ceil(H / 256) <= the same
+ * number for larger ones; beyond it the call fails with FX_EINVAL.  All calls
+ * on one device share the block: calls that overlap in time on one device
+ * (different streams or threads) race and must be ordered by the caller.
+ */
+#define FX_HU_NOALLOC_MAX_IMAGES 65536
+int fx_hu_batch_u8_noalloc(const uint8_t *d_img, int64_t B, int H, int W,
+                           int64_t pitch_bytes, int64_t img_stride_bytes,
+                           int thresh, int on_value,
+                           double *d_moments24, double *d_hu7, float *d_hulog7,
+                           int n_bins, float *d_cpca, double *d_ceig,
+                           void *stream);
+
+/*
  * Per-sample aggregation of the per-view rows (reference
  * src/features/extract_2d_hu.py:641-644: np.mean / np.std(ddof=0) over the
  * stacked float32 rows, concatenated to float32[14]), in NumPy's float32
