@@ -44,6 +44,9 @@ def run(job):
                 rows.append(c.hu_batch(pre[None])["hulog7"][0])
             rows = np.stack(rows).astype(np.float32)
             np.concatenate([rows.mean(axis=0), rows.std(axis=0)])
+    elif kind == "tail":
+        for img in data:
+            c.hu_batch(img[None], thresh=127, on_value=255)
     elif kind == "sil+hu":
         for img in data:
             mask, _ = cpu_ref.silhouette(img, 224, 0.05, True)

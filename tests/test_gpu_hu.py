@@ -280,3 +280,39 @@ def test_two_streams_overlap(gpu, c_oracle):
     pkg("_lib").call("fx_release_stream", int(s1.cuda_stream))
     pkg("_lib").call("fx_release_stream", int(s2.cuda_stream))
     torch.cuda.synchronize()
+
+
+def test_full_shard_125k_images(gpu, c_oracle):
+    """The benchmark's own launch: 125 000 x 512 x 512 (32.8 GB, 125 000
+    blocks) with the contour descriptor.  m00 against a torch count over every
+    image, additivity of the raw moments over a split of every image, finite
+    descriptors, and the oracle on rows from both ends of the grid."""
+    eng = pkg("engine")
+    B, H, W = 125_000, 512, 512
+    imgs = torch.empty((B, H, W), dtype=torch.uint8, device=gpu)
+    for a in range(0, B, 8192):
+        b = min(B, a + 8192)
+        eng.synth_shapes(b - a, H, W, seed=42, first_index=a, device=gpu, out=imgs[a:b])
+    res = eng.hu_batch(imgs, thresh=127, moments=True, hu=True, contour_bins=8)
+    counts = torch.empty(B, dtype=torch.float64, device=gpu)
+    for a in range(0, B, 4096):
+        counts[a:a + 4096] = (imgs[a:a + 4096] > 127).sum(dim=(1, 2)).double()
+    assert torch.equal(res["moments24"][:, 0], 255.0 * counts)
+    assert torch.all(torch.isfinite(res["hulog7"]))
+    few = counts < 3
+    assert torch.all(torch.isfinite(res["cpca"][~few]))
+    assert torch.all((res["cpca"][~few][:, 9:].sum(dim=1) - 1).abs() < 1e-5)
+    rows = list(range(4)) + [62_499, 62_500] + list(range(B - 4, B))
+    sel = torch.tensor(rows, device=gpu)
+    got = {k: res[k][sel].cpu().numpy() for k in ("moments24", "hu7", "hulog7")}
+    check_against_oracle(got, c_oracle.hu_batch(imgs[sel].cpu().numpy(), thresh=127))
+    # additivity: left half + right half of every image = the image (integers, so exactly)
+    whole = res["moments24"][:, :10].clone()
+    del res
+    half = imgs.clone()
+    half[:, :, W // 2:] = 0
+    ml = eng.hu_batch(half, thresh=127, moments=True)["moments24"][:, :10].clone()
+    half.copy_(imgs)
+    half[:, :, : W // 2] = 0
+    mr = eng.hu_batch(half, thresh=127, moments=True)["moments24"][:, :10]
+    assert torch.equal(ml + mr, whole)

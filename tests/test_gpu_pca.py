@@ -147,3 +147,30 @@ def test_full_size_properties(gpu):
     perm = pts[:, :, [2, 0, 1]].contiguous()
     eig2 = eng.pca_batch(perm, None, 8, False, eig=True)["eig"]
     assert torch.all((eig2[:, :3] - eig[:, :3]).abs() <= 1e-12 * eig[:, :1])
+
+
+def test_full_batch_one_million_sets(gpu, oracle):
+    """The whole C4 batch in one launch (250 000 blocks): invariants over all
+    rows, the oracle on rows from both ends and the middle of the grid, and
+    equality with the same sets computed in small launches."""
+    import torch
+    eng = pkg("engine")
+    B, N = 1_000_000, 1024
+    pts = eng.synth_points(B, N, seed=42, device=gpu)
+    res = eng.pca_batch(pts, None, 8, False, eig=True)
+    out, eig = res["out"], res["eig"]
+    assert torch.all(torch.isfinite(out))
+    assert torch.all((out[:, 9:].sum(dim=1) - 1).abs() < 1e-6)
+    assert torch.all((out[:, 3:6].sum(dim=1) - 1).abs() < 1e-6)
+    assert torch.all(eig[:, 0] >= eig[:, 1]) and torch.all(eig[:, 1] >= eig[:, 2]) and torch.all(eig[:, 2] >= 0)
+    rows = [0, 1, 2, 3, 4, 499_999, 500_000, B - 5, B - 4, B - 3, B - 2, B - 1]
+    sel = torch.tensor(rows, device=gpu)
+    host, o, e = pts[sel].cpu().numpy().astype(np.float64), out[sel].cpu().numpy(), eig[sel].cpu().numpy()
+    ties = 0
+    for k in range(len(rows)):
+        ref_out, ref_eig = oracle.compute_pca_features(host[k], 8, False, return_eig=True)
+        ties += compare_set(o[k], e[k], ref_out, ref_eig, N)
+    assert ties <= 2
+    # the tail of the grid computed again as a launch of its own: bit-identical rows
+    again = eng.pca_batch(pts[B - 4099:].contiguous(), None, 8, False, eig=True)
+    assert torch.equal(again["out"], out[B - 4099:]) and torch.equal(again["eig"], eig[B - 4099:])

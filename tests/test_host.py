@@ -1,5 +1,6 @@
 """Host-side logic of the package: preprocessing, CSV layouts, merge, sharding (no GPU)."""
 import hashlib
+import json
 import os
 import subprocess
 import sys
@@ -202,6 +203,30 @@ def test_all_gather_rows_world_size_2_gloo(tmp_path):
                        capture_output=True, text=True, env=env, timeout=240)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("ok") == 2
+
+
+def test_bench_gpus_flag_starts_its_own_ranks():
+    """`python bench.py --gpus 2` typed without a launcher: the parent starts
+    two ranks as child processes and relays rank 0's JSON line (rehearsed on
+    the CPU over gloo; no GPU is touched by the parent or by --dry-run)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True,
+                       text=True, env=env, timeout=240)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and lines[0]["dry_run"] is True and lines[0]["n_gpus"] == 2 and lines[0]["rows"] == 10
+    # the tail configuration's clouds: LPT keeps the ranks' point counts close
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fx_bench", ROOT / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    sizes = bench.tail_cloud_sizes()
+    assert sizes.shape == (64,) and sizes.min() >= 1000 and sizes.max() <= 4_000_000
+    loads = [int(sizes[a].sum()) for a in pkg("dist").lpt_assign([float(v) for v in sizes], 8)]
+    assert max(loads) <= 1.25 * (sum(loads) / 8) or max(loads) == int(sizes.max())
+    cmd = bench.launcher_command(bench.parse(["--gpus", "4"]), ["--gpus", "4"])
+    assert "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd and cmd[-2:] == ["--gpus", "4"]
 
 
 # ---------------------------------------------------------------- generator

@@ -14,8 +14,15 @@ from collections import defaultdict
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-DOMINANT = {"c3": "hu_band_kernel", "c2": "hu_band_kernel", "c4": "pca_sets_reg_kernel", "f1": "sil_mask_kernel"}
-UNITS = {"c3": (125000, 262144), "c2": (250000, 65536), "c4": (1000000, 12288), "f1": (20000, 50176)}
+DOMINANT = {"c3": "hu_band_kernel", "c2": "hu_band_kernel", "c4": "pca_sets_reg_kernel", "c5": "hu_band_kernel",
+            "f1": "sil_mask_kernel"}
+UNITS = {"c3": (125000, 262144), "c2": (100000, 65536), "c4": (1000000, 12288), "c5": (64, 67108864), "f1": (20000, 50176)}
+# FETCH_SIZE on gfx950 tallies the 128-byte requests of a 16 B/lane coalesced stream at 64 bytes, i.e. half the
+# bytes; other request mixes are uncalibrated.  The factor is applied only to kernels whose loads are all
+# 16 B/lane (hu_band_kernel: one global_load_dwordx4 per chunk; pca_sets_reg_kernel, aligned variant: three
+# float4 per lane), each of which reads its input exactly once, so the corrected figure can be checked against
+# the algorithmic byte count (ratio recorded below).  Kernels with another request mix get no traffic figure.
+FETCH_FACTOR = {"hu_band_kernel": 2.0, "pca_sets_reg_kernel": 2.0}
 
 
 def short(name):
@@ -55,7 +62,8 @@ def main():
     kernels = {k: {"FETCH_SIZE": fetch.get(k, 0.0), "WRITE_SIZE": write.get(k, 0.0)} for k in fetch if k.endswith("_kernel")}
     dom = DOMINANT[workload]
     units, bytes_per_unit = UNITS[workload]
-    hbm = 2.0 * kernels[dom]["FETCH_SIZE"] * 1024.0 + kernels[dom]["WRITE_SIZE"] * 1024.0
+    factor = FETCH_FACTOR.get(dom)
+    hbm = None if factor is None else factor * kernels[dom]["FETCH_SIZE"] * 1024.0 + kernels[dom]["WRITE_SIZE"] * 1024.0
     doc = {
         "command": "rocprofv3 --pmc <COUNTER> --output-format csv -- python3 bench.py --workload %s --steps 3 --warmup 1 "
                    "--no-cpu-baseline (one counter per run)" % workload,
@@ -64,6 +72,11 @@ def main():
         "kernels": kernels,
         dom + "_hbm_bytes_per_launch": hbm,
         "algorithmic_bytes_per_launch": units * bytes_per_unit,
+        "fetch_size_factor": factor,
+        "calibration": None if hbm is None else {
+            "what": "the kernel reads every input byte exactly once with 16 B/lane loads, so corrected traffic / "
+                    "algorithmic bytes should be 1; a factor of 1 would give about 0.5, a wrong request mix something else",
+            "traffic_over_algorithmic": hbm / (units * bytes_per_unit)},
     }
     (round_dir / f"{workload}_pmc_hbm.json").write_text(json.dumps(doc, indent=1))
     tfile = ROOT / "profiles" / "traffic.json"
