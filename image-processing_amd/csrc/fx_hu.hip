@@ -1216,23 +1216,23 @@ __global__ __launch_bounds__(FX_BLOCK) void hu_finalize_kernel(HuArgs A, BandScr
     }
 }
 
-// Tiled mode, one lane per image: shift every tile's local sums to image
-// coordinates and add them up in exact 128-bit integers, round each raw moment
+// Tiled mode, one wave per image: the lanes shift their tiles' local sums to
+// image coordinates and add them up in exact 128-bit integers (lane l takes
+// tiles l, l + 64, ...; a butterfly adds the lanes), each raw moment is rounded
 // once to double (for images up to 512 x 512 this is the value OpenCV's
 // double accumulation holds exactly; beyond, it is the value that accumulation
-// approximates), then finalise as usual.
-__global__ __launch_bounds__(FX_BLOCK) void hu_tile_combine_kernel(HuArgs A, BandScratch G, int gray)
+// approximates), then lane 0 finalises as usual.
+__global__ __launch_bounds__(FX_WAVE) void hu_tile_combine_kernel(HuArgs A, BandScratch G, int gray)
 {
     typedef unsigned __int128 u128;
-    const int64_t b = (int64_t)blockIdx.x * FX_BLOCK + threadIdx.x;
-    if (b >= A.B)
-        return;
+    const int64_t b = blockIdx.x;
+    const int lane = threadIdx.x;
     const int tiles = A.tiles_x * A.tiles_y;
     u128 M[10];
 #pragma unroll
     for (int k = 0; k < 10; k++)
         M[k] = 0;
-    for (int tile = 0; tile < tiles; tile++) {
+    for (int tile = lane; tile < tiles; tile += FX_WAVE) {
         const u64 *t = G.sums + (b * tiles + tile) * BAND_SUMS;
         const int tyi = tile / A.tiles_x, txi = tile - tyi * A.tiles_x;
         const u128 X = (u128)(txi * TILE_W), Y = (u128)(tyi * TILE_H) + (u128)(A.partial ? A.y_offset : 0);
@@ -1249,6 +1249,19 @@ __global__ __launch_bounds__(FX_BLOCK) void hu_tile_combine_kernel(HuArgs A, Ban
         M[8] += t12 + 2 * Y * t11 + Y * Y * t10 + X * t02 + 2 * X * Y * t01 + X * Y * Y * t00;
         M[9] += t03 + 3 * Y * t02 + 3 * Y * Y * t01 + Y * Y * Y * t00;
     }
+    if (tiles > 1) {
+#pragma unroll
+        for (int k = 0; k < 10; k++) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const u64 lo = (u64)__shfl_xor((unsigned long long)(u64)M[k], o, FX_WAVE);
+                const u64 hi = (u64)__shfl_xor((unsigned long long)(u64)(M[k] >> 64), o, FX_WAVE);
+                M[k] += ((u128)hi << 64) | lo;
+            }
+        }
+    }
+    if (lane != 0)
+        return;
     const u128 scale = gray ? 1 : (u128)A.on_value;
     if (A.partial) {
         const u64 limb = (1ull << 48) - 1;
@@ -1509,7 +1522,7 @@ int hu_batch_impl(const char *who, const HuScratch &scratch, const uint8_t *d_im
         }
         if (rc != FX_OK)
             return rc;
-        hipLaunchKernelGGL(hu_tile_combine_kernel, dim3((unsigned)((B + FX_BLOCK - 1) / FX_BLOCK)), dim3(FX_BLOCK), 0, s, A, G,
+        hipLaunchKernelGGL(hu_tile_combine_kernel, dim3((unsigned)B), dim3(FX_WAVE), 0, s, A, G,
                            mode == MODE_GRAY ? 1 : 0);
         FX_HIP_CHECK(hipGetLastError());
         return FX_OK;
@@ -1689,7 +1702,7 @@ extern "C" int fx_hu_partial_u8(const uint8_t *d_img, int64_t B, int H, int W, i
     }
     if (rc != FX_OK)
         return rc;
-    hipLaunchKernelGGL(hu_tile_combine_kernel, dim3((unsigned)((B + FX_BLOCK - 1) / FX_BLOCK)), dim3(FX_BLOCK), 0, s, A, G,
+    hipLaunchKernelGGL(hu_tile_combine_kernel, dim3((unsigned)B), dim3(FX_WAVE), 0, s, A, G,
                        mode == MODE_GRAY ? 1 : 0);
     FX_HIP_CHECK(hipGetLastError());
     return FX_OK;

@@ -829,27 +829,37 @@ __global__ __launch_bounds__(CLOUD_THREADS) void cloud_hist_kernel(PcaArgs A, Cl
         Wk.hpart[(int64_t)blockIdx.x * HIST_MAX + threadIdx.x] = hist[threadIdx.x];
 }
 
-// One wave per cloud: add the chunk histograms, normalise, write.
-__global__ __launch_bounds__(FX_WAVE) void cloud_finish_kernel(PcaArgs A, CloudWork Wk)
+// One block per cloud: add the chunk histograms (wave w takes chunks w, w + 4,
+// ..., lane = bin), normalise, write.  Integer sums, so the order is free.
+__global__ __launch_bounds__(FX_BLOCK) void cloud_finish_kernel(PcaArgs A, CloudWork Wk)
 {
-    const int cloud = blockIdx.x, lane = threadIdx.x;
+    __shared__ double tops[FX_WAVES_PER_BLOCK];
+    __shared__ u64 cnts[FX_WAVES_PER_BLOCK][HIST_MAX];
+    const int cloud = blockIdx.x, lane = fx_lane(), wave = fx_wave();
     const int first = Wk.cloud_first[cloud], nch = Wk.cloud_first[cloud + 1] - first;
     const int64_t set = Wk.cloud_ids[cloud];
     const int64_t n = A.offsets ? A.offsets[set + 1] - A.offsets[set] : A.N;
     double top = 0.0;
-    for (int i = 0; i < nch; i++)
+    for (int i = threadIdx.x; i < nch; i += FX_BLOCK)
         top = fmax(top, Wk.part[(int64_t)(first + i) * PART + 10]);
+    top = fx_wave_max_f64(top);
+    u64 cnt = 0;
+    for (int i = wave; i < nch; i += FX_WAVES_PER_BLOCK)
+        cnt += Wk.hpart[(int64_t)(first + i) * HIST_MAX + lane];
+    cnts[wave][lane] = cnt;
+    if (lane == 0)
+        tops[wave] = top;
+    __syncthreads();
     const int nb = A.n_bins;
-    if (lane >= nb)
+    if (wave != 0 || lane >= nb)
         return;
+    top = fmax(fmax(tops[0], tops[1]), fmax(tops[2], tops[3]));
     float *out = A.out + set * (9 + nb) + 9;
     if (!(top > 0.0)) {
         out[lane] = lane == 0 ? 1.0f : 0.0f;
         return;
     }
-    u64 cnt = 0;
-    for (int i = 0; i < nch; i++)
-        cnt += Wk.hpart[(int64_t)(first + i) * HIST_MAX + lane];
+    cnt = cnts[0][lane] + cnts[1][lane] + cnts[2][lane] + cnts[3][lane];
     out[lane] = (float)((double)cnt / (double)n);
 }
 
@@ -964,7 +974,7 @@ int launch_large_clouds(const PcaArgs &A, const int32_t *h_sets, const int64_t *
     hipLaunchKernelGGL(cloud_moment_kernel<1>, grid, block, 0, s, A, Wk);
     hipLaunchKernelGGL(cloud_proj_kernel, grid, block, 0, s, A, Wk);
     hipLaunchKernelGGL(cloud_hist_kernel, grid, block, 0, s, A, Wk);
-    hipLaunchKernelGGL(cloud_finish_kernel, dim3((unsigned)n_clouds), dim3(FX_WAVE), 0, s, A, Wk);
+    hipLaunchKernelGGL(cloud_finish_kernel, dim3((unsigned)n_clouds), dim3(FX_BLOCK), 0, s, A, Wk);
     FX_HIP_CHECK(hipGetLastError());
     return FX_OK;
 }

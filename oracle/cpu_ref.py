@@ -415,6 +415,259 @@ def preprocess_image(img: np.ndarray, resolution: int, crop_margin: float, bg_co
 
 
 # --------------------------------------------------------------------------
+# Silhouette preprocessing: the reference's branch WITH OpenCV
+# (src/features/extract_2d_hu.py:137-148 GaussianBlur + THRESH_OTSU, :171-177
+# 5x5 MORPH_ELLIPSE close x2 / open x1, :198-221 findContours EXTERNAL ->
+# largest contourArea -> boundingRect, :261-264 3x3 ellipse open, :284-297
+# connectedComponentsWithStats(connectivity=8)), the branch the production run
+# took.  OpenCV is a third-party dependency of the reference, version not
+# pinned (requirements.txt lists only tabulate) and not importable here; its
+# published algorithms (modules/imgproc: smooth.dispatch.cpp fixed-point
+# Gaussian, thresh.cpp getThreshVal_Otsu_8u, morph getStructuringElement /
+# morphOp, contours.cpp border following, shapeapprox contourArea,
+# connectedcomponents.cpp) are restated below.  PINNED by the reference's own
+# artefacts: on all 21 (raw view_01 -> gray crop, cleaned mask) panel pairs of
+# reports/sample_images/*_hu_preview.png (tests/golden/hu_panels.npz) this
+# restatement reproduces both panels with zero differing pixels.  The panels
+# discriminate the blur kernel / rounding / border, the erosion border, both
+# structuring elements and the largest-contour box; they do not discriminate
+# Otsu tie handling, 8- vs 4-connectivity of the final filter, contour area vs
+# pixel count, or the order among equal candidates: those follow OpenCV's
+# algorithm as published.
+# --------------------------------------------------------------------------
+CV_ELLIPSE5 = np.array([[0, 0, 1, 0, 0], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [0, 0, 1, 0, 0]], dtype=bool)
+CV_ELLIPSE3 = np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]], dtype=bool)   # what getStructuringElement gives for 3 x 3
+
+
+def cv_gaussian_blur5(img: np.ndarray) -> np.ndarray:
+    """cv2.GaussianBlur(img, (5, 5), 0) on an 8-bit image: sigma <= 0 with
+    ksize 5 selects the table kernel [1, 4, 6, 4, 1] / 16, applied in 8.8
+    fixed point along x (exact), then along y with one rounding,
+    (sum + 128) >> 8; BORDER_REFLECT_101."""
+    a = img.astype(np.int64)
+    h, w = a.shape
+    p = np.pad(a, 2, mode="reflect")
+    k = (1, 4, 6, 4, 1)
+    rows = sum(k[j] * p[:, j:j + w] for j in range(5))
+    tot = sum(k[j] * rows[j:j + h, :] for j in range(5))
+    return ((tot + 128) >> 8).astype(np.uint8)
+
+
+def cv_otsu_threshold(img: np.ndarray) -> int:
+    """getThreshVal_Otsu_8u: running class mean kept recursively in double,
+    classes lighter than FLT_EPSILON skipped, first strict maximum."""
+    h = np.bincount(img.ravel(), minlength=256).astype(np.float64)
+    scale = 1.0 / img.size
+    mu = 0.0
+    for i in range(256):
+        mu += i * h[i]
+    mu *= scale
+    eps = float(np.finfo(np.float32).eps)
+    mu1 = q1 = 0.0
+    best, level = 0.0, 0
+    for i in range(256):
+        p_i = h[i] * scale
+        mu1 *= q1
+        q1 += p_i
+        q2 = 1.0 - q1
+        if min(q1, q2) < eps or max(q1, q2) > 1.0 - eps:
+            continue
+        mu1 = (mu1 + i * p_i) / q1
+        mu2 = (mu - q1 * mu1) / q2
+        sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2)
+        if sigma > best:
+            best, level = sigma, i
+    return int(level)
+
+
+def cv_erode(b: np.ndarray, se: np.ndarray) -> np.ndarray:
+    """cv2.erode with the default border: pixels outside never lower the minimum."""
+    from scipy import ndimage as ndi
+    return ndi.binary_erosion(b, structure=se, border_value=1)
+
+
+def cv_dilate(b: np.ndarray, se: np.ndarray) -> np.ndarray:
+    """cv2.dilate with the default border: pixels outside never raise the maximum."""
+    from scipy import ndimage as ndi
+    return ndi.binary_dilation(b, structure=se, border_value=0)
+
+
+def cv_compute_otsu(img: np.ndarray):
+    """(threshold, inverted, boolean mask): reference :137-177 with cv2."""
+    blur = cv_gaussian_blur5(img)
+    thresh = cv_otsu_threshold(blur)
+    b = blur > thresh
+    inverted = bool(np.count_nonzero(b) / b.size > 0.5)
+    if inverted:
+        b = ~b
+    b = cv_dilate(cv_dilate(b, CV_ELLIPSE5), CV_ELLIPSE5)      # MORPH_CLOSE, iterations=2: dilate twice,
+    b = cv_erode(cv_erode(b, CV_ELLIPSE5), CV_ELLIPSE5)        # then erode twice
+    b = cv_dilate(cv_erode(b, CV_ELLIPSE5), CV_ELLIPSE5)       # MORPH_OPEN
+    return thresh, inverted, b
+
+
+def cv_fill_holes(b: np.ndarray) -> np.ndarray:
+    """Foreground plus every background pixel that is not 4-connected to the
+    image frame.  Its 8-connected components are the components that
+    findContours(RETR_EXTERNAL) reports (components nested in a hole of another
+    one disappear), each with its outer border unchanged."""
+    from scipy import ndimage as ndi
+    bg, _ = ndi.label(np.pad(~b, 1, constant_values=True))
+    return (bg != bg[0, 0])[1:-1, 1:-1]
+
+
+def cv_external_contours(b: np.ndarray):
+    """[(contourArea, (x, y, w, h), raster rank of the first pixel)] of the
+    external contours.  The border follower walks the boundary pixels of a
+    component with the background on one side; the shoelace sum of that closed
+    walk is a sum of local terms over the corners of the pixel grid: a step
+    between the two foreground pixels of a straight boundary corner, a diagonal
+    step between the two neighbours of the background pixel at a concave
+    corner (saddle corners contribute two opposite steps that cancel)."""
+    from scipy import ndimage as ndi
+    h, w = b.shape
+    filled = cv_fill_holes(b)
+    lab, n = ndi.label(filled, structure=np.ones((3, 3)))
+    if n == 0:
+        return []
+    L = np.pad(lab, 1)
+    A, B, C, D = L[:-1, :-1], L[:-1, 1:], L[1:, :-1], L[1:, 1:]   # pixels around corner (vy, vx): TL, TR, BL, BR
+    fa, fb, fc, fd = A > 0, B > 0, C > 0, D > 0
+    vy, vx = np.mgrid[0:h + 1, 0:w + 1]
+    ax, ay, bx, by, cx, cy, dx, dy = vx - 1, vy - 1, vx, vy - 1, vx - 1, vy, vx, vy
+    steps = [   # (corner pattern, from pixel, to pixel, label carrier): background kept on the same hand throughout
+        (fa & fb & ~fc & ~fd, (ax, ay), (bx, by), A), (fc & fd & ~fa & ~fb, (dx, dy), (cx, cy), C),
+        (fa & fc & ~fb & ~fd, (cx, cy), (ax, ay), A), (fb & fd & ~fa & ~fc, (bx, by), (dx, dy), B),
+        (fa & fb & fc & ~fd, (cx, cy), (bx, by), A), (fa & fb & fd & ~fc, (ax, ay), (dx, dy), A),
+        (fa & fc & fd & ~fb, (dx, dy), (ax, ay), A), (fb & fc & fd & ~fa, (bx, by), (cx, cy), B),
+    ]
+    twice = np.zeros(n + 1, dtype=np.int64)
+    for sel, (px, py), (qx, qy), carrier in steps:
+        np.add.at(twice, carrier[sel], (px * qy - py * qx)[sel])
+    first = ndi.minimum_position(np.arange(h * w).reshape(h, w), lab, index=range(1, n + 1))
+    boxes = ndi.find_objects(lab)
+    return [(abs(int(twice[k])) / 2.0,
+             (boxes[k - 1][1].start, boxes[k - 1][0].start, boxes[k - 1][1].stop - boxes[k - 1][1].start,
+              boxes[k - 1][0].stop - boxes[k - 1][0].start), first[k - 1][0] * w + first[k - 1][1])
+            for k in range(1, n + 1)]
+
+
+def cv_trace_outer_areas(b: np.ndarray) -> dict:
+    """Slow cross-check of cv_external_contours: follows the outer border of
+    every 8-connected component pixel by pixel (Suzuki-Abe border following as
+    findContours does) and returns {raster rank of first pixel: shoelace area}."""
+    from scipy import ndimage as ndi
+    h, w = b.shape
+    lab, n = ndi.label(b, structure=np.ones((3, 3)))
+    p = np.pad(b, 1)
+    ring = [(-1, 0), (-1, -1), (0, -1), (1, -1), (1, 0), (1, 1), (0, 1), (-1, 1)]  # clockwise from the left neighbour
+    out = {}
+    for k in range(1, n + 1):
+        ys, xs = np.nonzero(lab == k)
+        j = np.lexsort((xs, ys))[0]
+        sx, sy = int(xs[j]) + 1, int(ys[j]) + 1
+        key = (sy - 1) * w + (sx - 1)
+        start = None
+        for d in range(8):
+            if p[sy + ring[d][1], sx + ring[d][0]]:
+                start = d
+                break
+        if start is None:
+            out[key] = 0.0
+            continue
+        first_next = (sx + ring[start][0], sy + ring[start][1])
+        pts = [(sx, sy)]
+        prev, cur = first_next, (sx, sy)
+        while True:
+            d0 = ring.index((prev[0] - cur[0], prev[1] - cur[1]))
+            for step in range(1, 9):
+                d = (d0 - step) % 8
+                if p[cur[1] + ring[d][1], cur[0] + ring[d][0]]:
+                    break
+            nxt = (cur[0] + ring[d][0], cur[1] + ring[d][1])
+            if nxt == (sx, sy) and cur == first_next:
+                break
+            pts.append(nxt)
+            prev, cur = cur, nxt
+        twice = sum(pts[t - 1][0] * pts[t][1] - pts[t - 1][1] * pts[t][0] for t in range(len(pts)))
+        out[key] = abs(twice) / 2.0
+    return out
+
+
+def cv_find_largest_bbox(b: np.ndarray):
+    """x, y, w, h of the external contour with the largest contourArea
+    (reference :198-221).  cv2.findContours lists the contours in reverse order
+    of discovery and Python's max() keeps the first maximum, so among equal
+    areas the component found last in raster order wins."""
+    h, w = b.shape
+    best = None
+    for area, box, rank in cv_external_contours(b):
+        if best is None or area > best[0] or (area == best[0] and rank > best[2]):
+            best = (area, box, rank)
+    return (0, 0, w, h) if best is None else tuple(int(v) for v in best[1])
+
+
+def cv_clean_mask_np(mask_np: np.ndarray, resolution: int, min_size=None) -> np.ndarray:
+    """Reference :246-297 with cv2: 3x3 ellipse (= cross) opening, then
+    8-connected components below min_size dropped; when none reaches it the
+    largest is kept, the lowest label among equals.  OpenCV's labelling scans
+    2x2 blocks, so labels are ordered by the block-raster position of a
+    component's first block."""
+    from scipy import ndimage as ndi
+    if min_size is None:
+        min_size = max(8, int(0.001 * resolution * resolution))
+    b = mask_np > 127
+    b = cv_dilate(cv_erode(b, CV_ELLIPSE3), CV_ELLIPSE3)
+    lab, n = ndi.label(b, structure=np.ones((3, 3)))
+    if n == 0:
+        return b.astype(np.uint8) * 255
+    sizes = np.asarray(ndi.sum(b, lab, range(1, n + 1))).astype(np.int64)
+    keep = sizes >= min_size
+    if not keep.any():
+        ys, xs = np.nonzero(b)
+        block_rank = (ys >> 1) * (b.shape[1] + 1) + (xs >> 1)
+        first_block = np.asarray(ndi.minimum(block_rank, lab[ys, xs], range(1, n + 1)))
+        order = np.lexsort((first_block, -sizes))
+        keep[order[0]] = True
+    return np.isin(lab, 1 + np.nonzero(keep)[0]).astype(np.uint8) * 255
+
+
+def silhouette_cv(img: np.ndarray, resolution: int, crop_margin: float, preprocess_crop: bool, min_size=None):
+    """silhouette() on the reference's OpenCV branch: (cleaned 0/255
+    silhouette, info) with info = [Otsu level, inverted, crop x0, y0, x1, y1,
+    resized width, height] (reference :352-440)."""
+    from PIL import Image
+    h, w = img.shape[:2]
+    thresh, inverted, b = cv_compute_otsu(img)
+    mask = b.astype(np.uint8) * 255
+    x0, y0, x1, y1 = 0, 0, w, h
+    if preprocess_crop:
+        x, y, ww, hh = cv_find_largest_bbox(b)
+        side = max(ww, hh)
+        pad = int(round(crop_margin * side)) if crop_margin <= 1.0 else int(round(crop_margin))
+        x0, y0 = max(0, x - pad), max(0, y - pad)
+        x1, y1 = min(w, x + ww + pad), min(h, y + hh + pad)
+        if x1 <= x0 or y1 <= y0:
+            x0, y0, x1, y1 = 0, 0, w, h
+    pil = Image.fromarray(mask[y0:y1, x0:x1]).convert("L")
+    scale = min(resolution / float(pil.width), resolution / float(pil.height))
+    new_w = max(1, int(round(pil.width * scale)))
+    new_h = max(1, int(round(pil.height * scale)))
+    small = np.asarray(pil.resize((new_w, new_h), resample=Image.NEAREST), dtype=np.uint8)
+    small = cv_clean_mask_np((small > 128).astype(np.uint8) * 255, resolution, min_size)
+    canvas = Image.new("L", (resolution, resolution), color=0)
+    canvas.paste(Image.fromarray(small).convert("L"), ((resolution - new_w) // 2, (resolution - new_h) // 2))
+    return np.asarray(canvas, dtype=np.uint8), np.array([thresh, int(inverted), x0, y0, x1, y1, new_w, new_h], dtype=np.int32)
+
+
+def preprocess_image_cv(img: np.ndarray, resolution: int, crop_margin: float, bg_color: str, preprocess_crop: bool):
+    """preprocess_image() on the reference's OpenCV branch."""
+    mask, info = silhouette_cv(img, resolution, crop_margin, preprocess_crop)
+    x0, y0, x1, y1 = (int(v) for v in info[2:6])
+    return pad_and_resize(img[y0:y1, x0:x1], resolution, bg_color), mask
+
+
+# --------------------------------------------------------------------------
 # Point-cloud normalisation and farthest point sampling
 # (reference src/preprocessing/prepare_all.py:199-217, :250-293), restated.
 # Pinned by tests/golden/fps_golden.npz, which holds the reference's outputs.

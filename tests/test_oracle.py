@@ -148,6 +148,123 @@ def test_silhouette_restatement_equals_reference_outputs(oracle):
             assert info[0] == t and 0 <= info[2] < info[4] <= img.shape[1] and 0 <= info[3] < info[5] <= img.shape[0]
 
 
+def test_opencv_branch_reproduces_the_production_panels(oracle, c_oracle, hu_panels):
+    """The 21 preview collages the reference committed hold, for view_01 of 21
+    ids, the raw view, the gray crop and the cleaned silhouette its production
+    run (OpenCV branch) computed: genuine input/output pairs.  The restatement
+    of that branch reproduces both outputs with zero differing pixels, and the
+    log-Hu of its masks sits where the committed feature table says."""
+    rows = {r["id"]: r for r in csv.DictReader(open(GOLDEN / "hu_table_rows.csv"))}
+    for i, sid in enumerate(hu_panels["ids"]):
+        raw = hu_panels["raw_views"][i, 0]
+        gray, mask = oracle.preprocess_image_cv(raw.copy(), 224, 0.05, "white", True)
+        np.testing.assert_array_equal(gray, hu_panels["preproc"][i], err_msg=f"gray crop of {sid}")
+        np.testing.assert_array_equal(mask, hu_panels["masks"][i], err_msg=f"mask of {sid}")
+        hu = c_oracle.hu_batch(mask[None])["hulog7"][0]
+        assert abs(hu[0] - float(rows[sid]["hu1_mean"])) < 0.4
+    # the branch without OpenCV does not: it is a different algorithm (other blur, 3x3 box elements, box of all pixels)
+    differing = sum(int((oracle.preprocess_image(hu_panels["raw_views"][i, 0].copy(), 224, 0.05, "white", True)[1]
+                         != hu_panels["masks"][i]).any()) for i in range(21))
+    assert differing == 21
+
+
+def test_opencv_branch_building_blocks(oracle):
+    rng = np.random.default_rng(11)
+    # blur: constant images stay constant, an impulse spreads to the outer product of [1 4 6 4 1] / 256 (rounded half up)
+    assert np.all(oracle.cv_gaussian_blur5(np.full((9, 7), 201, np.uint8)) == 201)
+    imp = np.zeros((9, 9), np.uint8)
+    imp[4, 4] = 255
+    k = np.array([1, 4, 6, 4, 1])
+    np.testing.assert_array_equal(oracle.cv_gaussian_blur5(imp)[2:7, 2:7], (255 * np.outer(k, k) + 128) >> 8)
+    for shape in ((1, 1), (1, 6), (2, 2), (3, 5)):     # reflection without the edge pixel also on tiny images
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        assert oracle.cv_gaussian_blur5(img).shape == shape
+    # Otsu: two well separated classes; a constant image keeps level 0
+    two = np.concatenate([np.full(500, 40, np.uint8), np.full(300, 200, np.uint8)]).reshape(20, 40)
+    assert oracle.cv_otsu_threshold(two) == 40
+    assert oracle.cv_otsu_threshold(np.full((8, 8), 77, np.uint8)) == 0
+    # erosion treats the outside as foreground, dilation as background
+    full = np.ones((6, 6), bool)
+    assert oracle.cv_erode(full, oracle.CV_ELLIPSE5).all()
+    dot = np.zeros((7, 7), bool)
+    dot[0, 0] = True
+    assert int(oracle.cv_dilate(dot, oracle.CV_ELLIPSE5).sum()) == 3 + 3 + 1   # rows 0, 1 (three wide) and the tip at row 2
+    # contour areas from corner terms equal the pixel-by-pixel border follower's
+    for _ in range(120):
+        h, w = rng.integers(1, 15, 2)
+        b = rng.random((h, w)) < rng.choice([0.2, 0.5, 0.8])
+        traced = oracle.cv_trace_outer_areas(b)
+        for area, box, rank in oracle.cv_external_contours(b):
+            assert traced[rank] == area
+    # nested: a blob inside a ring is not an external contour; the ring's area is that of its outer border
+    ring = np.zeros((12, 12), bool)
+    ring[1:11, 1:11] = True
+    ring[3:9, 3:9] = False
+    ring[5:7, 5:7] = True
+    cands = oracle.cv_external_contours(ring)
+    assert len(cands) == 1 and cands[0][0] == 81.0 and cands[0][1] == (1, 1, 10, 10)
+    assert oracle.cv_find_largest_bbox(np.zeros((5, 8), bool)) == (0, 0, 8, 5)
+    # equal areas: the component found last wins
+    two = np.zeros((10, 10), bool)
+    two[1:4, 1:4] = True
+    two[6:9, 5:8] = True
+    assert oracle.cv_find_largest_bbox(two) == (5, 6, 3, 3)
+    # final filter: 8-connected (a diagonal chain is one component), cross-shaped opening
+    m = np.zeros((14, 14), np.uint8)
+    for cy, cx in ((5, 5), (7, 7)):       # two plus signs (unchanged by the cross opening) that touch diagonally
+        m[cy, cx - 1:cx + 2] = 255
+        m[cy - 1:cy + 2, cx] = 255
+    out = oracle.cv_clean_mask_np(m, 224, min_size=8)
+    np.testing.assert_array_equal(out, m)    # one component of 10 pixels; 4-connectivity would see two of 5
+    sq = np.zeros((20, 20), np.uint8)
+    sq[5:15, 5:15] = 255
+    assert int((oracle.cv_clean_mask_np(sq, 224, min_size=8) > 0).sum()) == 96   # the opening takes the four corners
+    # none reaches min_size: the largest is kept, the lowest label (2x2-block raster order) among equals
+    m = np.zeros((12, 20), np.uint8)
+    m[1:4, 10:13] = 255     # pixel-raster first
+    m[2:5, 2:5] = 255       # same block row pair for its first row? no: starts at row 2 -> block row 1
+    out = oracle.cv_clean_mask_np(m, 224, min_size=100)
+    assert out[2, 11] == 255 and out[3, 3] == 0
+
+
+def test_opencv_itself_when_present(oracle, c_oracle, hu_panels):
+    """Runs only where OpenCV is importable (not in the build image): the
+    library itself against the restatements, bit for bit."""
+    cv2 = pytest.importorskip("cv2")
+    synth = pkg("synth")
+    imgs = np.concatenate([hu_panels["masks"], hu_panels["preproc"], hu_panels["raw_views"][:, 0],
+                           synth.shapes_host(6, 224, 224, seed=3)])
+    ref = c_oracle.hu_batch(imgs)
+    for i, img in enumerate(imgs):
+        m = cv2.moments(img)
+        rec = np.array([m[k] for k in ("m00", "m10", "m01", "m20", "m11", "m02", "m30", "m21", "m12", "m03", "mu20", "mu11",
+                                       "mu02", "mu30", "mu21", "mu12", "mu03", "nu20", "nu11", "nu02", "nu30", "nu21",
+                                       "nu12", "nu03")])
+        np.testing.assert_array_equal(rec, ref["moments24"][i])
+        np.testing.assert_array_equal(cv2.HuMoments(m).ravel(), ref["hu7"][i])
+    k5 = cv2.getStructuringElement(cv2.MORPH_ELLIPSE, (5, 5))
+    k3 = cv2.getStructuringElement(cv2.MORPH_ELLIPSE, (3, 3))
+    np.testing.assert_array_equal(k5.astype(bool), oracle.CV_ELLIPSE5)
+    np.testing.assert_array_equal(k3.astype(bool), oracle.CV_ELLIPSE3)
+    for raw in hu_panels["raw_views"].reshape(-1, 224, 224):
+        blur = cv2.GaussianBlur(raw, (5, 5), 0)
+        np.testing.assert_array_equal(blur, oracle.cv_gaussian_blur5(raw))
+        t, mask = cv2.threshold(blur, 0, 255, cv2.THRESH_BINARY + cv2.THRESH_OTSU)
+        assert int(t) == oracle.cv_otsu_threshold(blur)
+        thresh, inverted, b = oracle.cv_compute_otsu(raw)
+        if np.count_nonzero(mask) / mask.size > 0.5:
+            mask = 255 - mask
+        mask = cv2.morphologyEx(mask, cv2.MORPH_CLOSE, k5, iterations=2)
+        mask = cv2.morphologyEx(mask, cv2.MORPH_OPEN, k5, iterations=1)
+        np.testing.assert_array_equal(mask > 127, b)
+        found = cv2.findContours(mask.copy(), cv2.RETR_EXTERNAL, cv2.CHAIN_APPROX_SIMPLE)
+        contours = found[0] if len(found) == 2 else found[1]
+        if len(contours):
+            best = max(contours, key=cv2.contourArea)
+            assert tuple(cv2.boundingRect(best)) == oracle.cv_find_largest_bbox(b)
+            assert sorted(cv2.contourArea(c) for c in contours) == sorted(a for a, _, _ in oracle.cv_external_contours(b))
+
+
 def test_pil_gaussian_blur_written_out(oracle):
     """The integer form of PIL's GaussianBlur(radius=1) that the device kernel follows."""
     from PIL import Image, ImageFilter
