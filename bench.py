@@ -139,8 +139,8 @@ def cpu_baseline(kind: str, sample, cores: int) -> dict:
             "kind": "port",
             "sample": f"{units} units of the benchmark's own synthetic data, {wall:.1f} s wall on {len(jobs)} worker processes "
                       f"(C restatement of cv2.moments/HuMoments + NumPy cov/eigh/histogram per unit"
-                      + ("; PIL + scipy.ndimage silhouette as in the reference" if kind == "sil+hu" else "")
-                      + ("; NumPy restatement of the matplotlib renderer, 12 views per cloud, PIL + scipy.ndimage preprocessing"
+                      + ("; NumPy/scipy restatement of the reference's OpenCV silhouette branch" if kind == "sil+hu" else "")
+                      + ("; NumPy restatement of the matplotlib renderer, 12 views per cloud, restated OpenCV-branch preprocessing"
                          if kind == "views+hu" else "")
                       + ("; 8192x8192 images only, the clouds are not part of this sample" if kind == "tail" else "") + ")"}
 
@@ -200,7 +200,7 @@ def verify(kind: str, state: dict, feats) -> dict:
         host = data[torch.from_numpy(idx).to(data.device)].cpu().numpy()
         got = feats[torch.from_numpy(idx).to(feats.device)].cpu().numpy()
         for k in range(len(idx)):
-            mask, _ = cpu_ref.silhouette(host[k], 224, 0.05, True)
+            mask, _ = cpu_ref.silhouette_cv(host[k], 224, 0.05, True)
             ref = c.hu_batch(mask[None])["hulog7"][0]
             ok &= bool(np.all(np.abs(got[k] - ref) <= np.spacing(np.abs(ref))))
         rows = len(idx)
@@ -215,7 +215,7 @@ def verify(kind: str, state: dict, feats) -> dict:
             r = []
             for pose in cpu_ref.compute_camera_poses(12, mins, maxs, cen):
                 view = cpu_ref.render_view(p64, pose, 224, stamp)
-                pre, _ = cpu_ref.preprocess_image(view, 224, 0.05, "white", False)
+                pre, _ = cpu_ref.preprocess_image_cv(view, 224, 0.05, "white", False)
                 r.append(c.hu_batch(pre[None])["hulog7"][0])
             r = np.stack(r).astype(np.float32)
             want = np.concatenate([r.mean(axis=0), r.std(axis=0)])

@@ -177,7 +177,7 @@ int fx_release_stream(void *stream)
 
 const char *fx_last_error(void) { return g_err; }
 
-int fx_abi_version(void) { return 1; }
+int fx_abi_version(void) { return 2; }
 
 int fx_profile(int enable)
 {

@@ -51,6 +51,8 @@ struct SilArgs {
     int wpr;          // words per row of the LDS masks
     int rows;         // rows of the LDS masks
     int tr;           // output rows per blur tile
+    int mode;         // FX_SIL_PIL or FX_SIL_OPENCV: which branch of the reference is reproduced
+    int32_t *level;   // [B] Otsu level, written by sil_otsu_cv_kernel (OpenCV branch)
 };
 
 __device__ __forceinline__ uint32_t sil_tap(uint32_t l, uint32_t c, uint32_t r)
@@ -230,6 +232,191 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_blur_kernel(SilArgs A)
         atomicAdd(&A.hist[b * 256 + threadIdx.x], h);
 }
 
+// ---------------------------------------------------------------------------
+// OpenCV branch, blur: cv2.GaussianBlur(img, (5, 5), 0) on 8-bit data is the
+// table kernel [1 4 6 4 1] / 16 in fixed point: exact sums along x (at most
+// 255 * 16), then along y with one rounding, (sum + 128) >> 8, borders
+// reflected without repeating the edge pixel (BORDER_REFLECT_101).
+// ---------------------------------------------------------------------------
+constexpr int SIL_CV_HALO = 2;
+
+__device__ __forceinline__ int sil_refl101(int i, int n)
+{
+    if (n == 1)
+        return 0;
+    while (i < 0 || i >= n)
+        i = i < 0 ? -i : 2 * (n - 1) - i;
+    return i;
+}
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(FX_BLOCK) void sil_blur_cv_kernel(SilArgs A)
+{
+    extern __shared__ __align__(16) uint8_t sil_smem[];
+    const int W = A.W, H = A.H;
+    const int Wp = (W + 15) & ~15;
+    const int cpr = Wp >> 4;
+    const int64_t b = blockIdx.y;
+    const int r0 = blockIdx.x * A.tr;
+    const int nrows = H - r0 < A.tr ? H - r0 : A.tr;           // rows this tile writes
+    const int trows = nrows + 2 * SIL_CV_HALO;
+    uint16_t *tile = (uint16_t *)sil_smem;                                        // [tr + 4][Wp] sums along x
+    uint32_t *hist = (uint32_t *)(sil_smem + (size_t)(A.tr + 2 * SIL_CV_HALO) * Wp * 2);  // [256]
+    const uint8_t *src = A.img + b * A.stride;
+    hist[threadIdx.x] = 0;
+
+    // along x: 16 pixels + 2 on each side in registers; tile row i is image row reflect(r0 - 2 + i)
+    for (int it = threadIdx.x; it < trows * cpr; it += FX_BLOCK) {
+        const int i = it / cpr, c = it - i * cpr;
+        const uint8_t *row = src + (int64_t)sil_refl101(r0 - SIL_CV_HALO + i, H) * A.pitch;
+        const int x0 = c * 16;
+        uint32_t v[20];
+        if (ALIGNED) {   // W is a multiple of 16 (so at least 16) and rows are 16-byte aligned
+            const uint4 m = *(const uint4 *)(row + x0);
+            const uint32_t mw[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                v[2 + k] = (mw[k >> 2] >> (8 * (k & 3))) & 255u;
+            if (x0 > 0) {
+                const uint32_t l = *(const uint32_t *)(row + x0 - 4);
+                v[0] = (l >> 16) & 255u;
+                v[1] = l >> 24;
+            } else {
+                v[0] = v[4];   // x = -2 -> 2
+                v[1] = v[3];   // x = -1 -> 1
+            }
+            if (x0 + 16 < W) {
+                const uint32_t r = *(const uint32_t *)(row + x0 + 16);
+                v[18] = r & 255u;
+                v[19] = (r >> 8) & 255u;
+            } else {
+                v[18] = v[16];  // x = W -> W - 2
+                v[19] = v[15];  // x = W + 1 -> W - 3
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 20; k++)
+                v[k] = row[sil_refl101(x0 - SIL_CV_HALO + k, W)];
+        }
+        uint32_t o[8];
+#pragma unroll
+        for (int k = 0; k < 16; k += 2) {
+            const uint32_t lo = v[k] + v[k + 4] + 4u * (v[k + 1] + v[k + 3]) + 6u * v[k + 2];
+            const uint32_t hi = v[k + 1] + v[k + 5] + 4u * (v[k + 2] + v[k + 4]) + 6u * v[k + 3];
+            o[k >> 1] = lo | (hi << 16);
+        }
+        uint4 *dst = (uint4 *)(tile + (size_t)i * Wp + x0);
+        dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+        dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+    }
+    __syncthreads();
+
+    // along y: a thread takes four neighbouring columns (two packed pairs of 16-bit sums; the largest total,
+    // 255 * 256 + 128, still fits 16 bits, so both halves of a word are summed at once) and a stretch of rows
+    const int quads = Wp >> 2;
+    int segs = FX_BLOCK / quads;
+    segs = segs < 1 ? 1 : segs;
+    const int rps = (nrows + segs - 1) / segs;
+    uint8_t *out = A.blur + b * (int64_t)H * W;
+    const bool row_dwords = (W & 3) == 0;
+    for (int it = threadIdx.x; it < quads * segs; it += FX_BLOCK) {
+        const int q = it % quads, y0 = (it / quads) * rps;
+        const int y1 = y0 + rps < nrows ? y0 + rps : nrows;
+        if (y0 >= y1 || 4 * q >= W)
+            continue;
+        const uint16_t *col = tile + 4 * q;
+        auto ld = [&](int i) { return *(const uint2 *)(col + (size_t)i * Wp); };
+        uint2 c0 = ld(y0), c1 = ld(y0 + 1), c2 = ld(y0 + 2), c3 = ld(y0 + 3);
+        uint32_t prev = 0, rep = 0;
+        auto flush = [&]() {
+            if (!rep)
+                return;
+            const uint32_t p0 = prev & 255u, p1 = (prev >> 8) & 255u, p2 = (prev >> 16) & 255u, p3 = prev >> 24;
+            const int live = W - 4 * q;  // columns of this quad inside the image
+            if (live >= 4 && p0 == p1 && p0 == p2 && p0 == p3) {
+                atomicAdd(&hist[p0], 4u * rep);
+            } else {
+                atomicAdd(&hist[p0], rep);
+                if (live > 1)
+                    atomicAdd(&hist[p1], rep);
+                if (live > 2)
+                    atomicAdd(&hist[p2], rep);
+                if (live > 3)
+                    atomicAdd(&hist[p3], rep);
+            }
+            rep = 0;
+        };
+        for (int y = y0; y < y1; y++) {
+            const uint2 c4 = ld(y + 4);
+            const uint32_t ta = c0.x + c4.x + 4u * (c1.x + c3.x) + 6u * c2.x + 0x00800080u;
+            const uint32_t tb = c0.y + c4.y + 4u * (c1.y + c3.y) + 6u * c2.y + 0x00800080u;
+            const uint32_t o = ((ta >> 8) & 255u) | ((ta >> 24) << 8) | (((tb >> 8) & 255u) << 16) | ((tb >> 24) << 24);
+            uint8_t *po = out + (int64_t)(r0 + y) * W + 4 * q;
+            if (row_dwords) {
+                *(uint32_t *)po = o;
+            } else {
+                for (int k = 0; k < 4 && 4 * q + k < W; k++)
+                    po[k] = (uint8_t)(o >> (8 * k));
+            }
+            if (o != prev) {
+                flush();
+                prev = o;
+            }
+            rep++;
+            c0 = c1;
+            c1 = c2;
+            c2 = c3;
+            c3 = c4;
+        }
+        flush();
+    }
+    __syncthreads();
+    const uint32_t h = hist[threadIdx.x];
+    if (h)
+        atomicAdd(&A.hist[b * 256 + threadIdx.x], h);
+}
+
+// OpenCV's Otsu level (getThreshVal_Otsu_8u): the class mean is carried from
+// level to level in double, so the 256 steps are a serial chain of roundings;
+// a lane per image runs it, 64 histograms staged through LDS per block.
+constexpr int SIL_OTSU_PITCH = 257;
+__global__ __launch_bounds__(FX_WAVE) void sil_otsu_cv_kernel(const uint32_t *hist, int64_t B, double scale, int32_t *level)
+{
+    extern __shared__ __align__(16) uint8_t sil_smem[];
+    uint32_t *h = (uint32_t *)sil_smem;  // [64][257]
+    const int64_t b0 = (int64_t)blockIdx.x * FX_WAVE;
+    const int n = B - b0 < FX_WAVE ? (int)(B - b0) : FX_WAVE;
+    for (int i = threadIdx.x; i < n * 256; i += FX_WAVE)
+        h[(i >> 8) * SIL_OTSU_PITCH + (i & 255)] = hist[b0 * 256 + i];
+    __syncthreads();
+    if ((int)threadIdx.x >= n)
+        return;
+    const uint32_t *mine = h + threadIdx.x * SIL_OTSU_PITCH;
+    double mu = 0.0;
+    for (int i = 0; i < 256; i++)
+        mu += (double)i * (double)mine[i];
+    mu *= scale;
+    const double eps = 1.1920928955078125e-07;  // FLT_EPSILON
+    double mu1 = 0.0, q1 = 0.0, max_sigma = 0.0;
+    int max_val = 0;
+    for (int i = 0; i < 256; i++) {
+        const double p_i = (double)mine[i] * scale;
+        mu1 *= q1;
+        q1 += p_i;
+        const double q2 = 1.0 - q1;
+        if (fmin(q1, q2) < eps || fmax(q1, q2) > 1.0 - eps)
+            continue;
+        mu1 = (mu1 + (double)i * p_i) / q1;
+        const double mu2 = (mu - q1 * mu1) / q2;
+        const double sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
+        if (sigma > max_sigma) {
+            max_sigma = sigma;
+            max_val = i;
+        }
+    }
+    level[b0 + threadIdx.x] = max_val;
+}
+
 // ------------------------------------------------------------ mask kernel
 // 3x3 dilation or erosion of a bit mask, scipy.ndimage semantics with
 // border_value = 0: whatever lies outside the rows x cols rectangle is
@@ -268,6 +455,76 @@ __device__ void sil_morph(const uint32_t *s, uint32_t *d, int rows, int cols, in
             d[y * wpr + w] = acc;
             ha = hb;
             hb = hc;
+        }
+    }
+    __syncthreads();
+}
+
+// OpenCV morphology on a bit mask: the 5 x 5 MORPH_ELLIPSE element (the centre
+// column in rows -2 and +2, five wide in rows -1, 0, +1) or the 3 x 3 one (a
+// cross), with cv2's default border: pixels outside the image never decide,
+// i.e. they count as foreground for an erosion and as background for a
+// dilation.  Bits at or beyond `cols` are zero in the result.
+template <bool DILATE, bool FIVE>
+__device__ void sil_morph_cv(const uint32_t *s, uint32_t *d, int rows, int cols, int wpr)
+{
+    const int wc = (cols + 31) >> 5;
+    const uint32_t lastmask = (cols & 31) ? ((1u << (cols & 31)) - 1u) : ~0u;
+    const uint32_t fill = DILATE ? 0u : ~0u;
+    int strips = FX_BLOCK / wc;
+    strips = strips < 1 ? 1 : strips;
+    const int rs = (rows + strips - 1) / strips;
+    for (int it = threadIdx.x; it < wc * strips; it += FX_BLOCK) {
+        const int w = it % wc, y0 = (it / wc) * rs;
+        if (y0 >= rows)
+            continue;
+        const int y1 = y0 + rs < rows ? y0 + rs : rows;
+        auto word = [&](int yy, int ww) -> uint32_t {
+            if (yy < 0 || yy >= rows || ww < 0 || ww >= wc)
+                return fill;
+            uint32_t m = s[yy * wpr + ww];
+            if (!DILATE && ww == wc - 1)
+                m |= ~lastmask;
+            return m;
+        };
+        auto centre = [&](int yy) -> uint32_t { return word(yy, w); };
+        auto wide = [&](int yy) -> uint32_t {
+            const uint32_t m = word(yy, w), p = word(yy, w - 1), n = word(yy, w + 1);
+            const uint32_t l1 = (m << 1) | (p >> 31), r1 = (m >> 1) | (n << 31);
+            if (!FIVE)
+                return DILATE ? (m | l1 | r1) : (m & l1 & r1);
+            const uint32_t l2 = (m << 2) | (p >> 30), r2 = (m >> 2) | (n << 30);
+            return DILATE ? (m | l1 | r1 | l2 | r2) : (m & l1 & r1 & l2 & r2);
+        };
+        if (FIVE) {
+            uint32_t cm2 = centre(y0 - 2), wm1 = wide(y0 - 1), w0 = wide(y0), wp1 = wide(y0 + 1);
+            uint32_t cm1 = centre(y0 - 1), c0 = centre(y0), cp1 = centre(y0 + 1);  // centre words of rows that later are row -2
+            for (int y = y0; y < y1; y++) {
+                const uint32_t cp2 = centre(y + 2);
+                uint32_t acc = DILATE ? (cm2 | wm1 | w0 | wp1 | cp2) : (cm2 & wm1 & w0 & wp1 & cp2);
+                if (w == wc - 1)
+                    acc &= lastmask;
+                d[y * wpr + w] = acc;
+                cm2 = cm1;
+                cm1 = c0;
+                c0 = cp1;
+                cp1 = cp2;
+                wm1 = w0;
+                w0 = wp1;
+                wp1 = wide(y + 2);
+            }
+        } else {
+            uint32_t cm1 = centre(y0 - 1), w0 = wide(y0), c0 = centre(y0);
+            for (int y = y0; y < y1; y++) {
+                const uint32_t cp1 = centre(y + 1);
+                uint32_t acc = DILATE ? (cm1 | w0 | cp1) : (cm1 & w0 & cp1);
+                if (w == wc - 1)
+                    acc &= lastmask;
+                d[y * wpr + w] = acc;
+                cm1 = c0;
+                c0 = cp1;
+                w0 = wide(y + 1);
+            }
         }
     }
     __syncthreads();
@@ -329,6 +586,163 @@ __device__ __forceinline__ uint32_t sil_spread4(uint32_t nib)
     return (__umul24(nib, 0x00204081u) & 0x01010101u) * 255u;
 }
 
+// First pixels of the runs of word w of a mask row.
+__device__ __forceinline__ uint32_t sil_starts(const uint32_t *row, int w)
+{
+    const uint32_t m = row[w], p = w > 0 ? row[w - 1] : 0u;
+    return m & ~((m << 1) | (p >> 31));
+}
+
+// Index of the run that holds the set pixel (x, y); pre[y * wc + w] is the
+// number of runs that start before word w of row y in raster order.
+__device__ __forceinline__ uint32_t sil_run_at(const uint32_t *m, const uint32_t *pre, int y, int x, int wc, int wpr)
+{
+    const int w = x >> 5;
+    return pre[y * wc + w] + __popc(sil_starts(m + y * wpr, w) & sil_le(x & 31)) - 1u;
+}
+
+struct SilRuns {
+    uint32_t *parent;  // root of every run after sil_label (the smallest run index of its component)
+    uint32_t *val;     // zeroed: per-root accumulator (size, flag or twice the contour area)
+    int n;
+};
+
+// Connected components over the row runs of a bit mask (rows x wc words, row
+// pitch wpr): a run is named by the raster-order rank of its first pixel, runs
+// of neighbouring rows that touch (sharing a column, or for CONN8 also
+// diagonally) are united lock-free, then every run is pointed at its root.
+// Every thread of the block calls this; the result is block-uniform.
+__device__ SilRuns sil_label(const uint32_t *m, int rows, int wc, int wpr, bool conn8, uint32_t *pre, uint32_t *s_scan,
+                             int *s_nruns, uint32_t *lds_runs, uint32_t *glob_runs, int run_cap)
+{
+    const int t = threadIdx.x;
+    const int nw = rows * wc;
+    const int per = (nw + FX_BLOCK - 1) / FX_BLOCK;
+    __syncthreads();
+    {
+        uint32_t local = 0;
+        for (int j = 0; j < per; j++) {
+            const int wi = t * per + j;
+            if (wi < nw) {
+                const int y = wi / wc, w = wi - y * wc;
+                local += __popc(sil_starts(m + y * wpr, w));
+            }
+        }
+        // exclusive prefix over the block: wave scan, then the waves in front
+        uint32_t inc = local;
+#pragma unroll
+        for (int o = 1; o < FX_WAVE; o <<= 1) {
+            const uint32_t u = __shfl_up(inc, o, FX_WAVE);
+            if (fx_lane() >= o)
+                inc += u;
+        }
+        if (fx_lane() == FX_WAVE - 1)
+            s_scan[fx_wave()] = inc;
+        s_scan[16 + t] = inc - local;
+    }
+    __syncthreads();
+    {
+        uint32_t base = s_scan[16 + t], total = 0;
+#pragma unroll
+        for (int w = 0; w < FX_WAVES_PER_BLOCK; w++) {
+            base += w < fx_wave() ? s_scan[w] : 0u;
+            total += s_scan[w];
+        }
+        for (int j = 0; j < per; j++) {
+            const int wi = t * per + j;
+            if (wi < nw) {
+                const int y = wi / wc, w = wi - y * wc;
+                pre[wi] = base;
+                base += __popc(sil_starts(m + y * wpr, w));
+            }
+        }
+        if (t == 0)
+            *s_nruns = (int)total;
+    }
+    __syncthreads();
+    SilRuns R;
+    R.n = *s_nruns;
+    R.parent = R.n <= SIL_RUNS_LDS ? lds_runs : glob_runs;
+    R.val = R.n <= SIL_RUNS_LDS ? lds_runs + SIL_RUNS_LDS : glob_runs + run_cap;
+    uint32_t *parent = R.parent;
+    for (int r = t; r < R.n; r += FX_BLOCK) {
+        parent[r] = (uint32_t)r;
+        R.val[r] = 0u;
+    }
+    __syncthreads();
+    for (int wi = t + wc; wi < nw; wi += FX_BLOCK) {
+        const int y = wi / wc, w = wi - y * wc;
+        const uint32_t *row = m + y * wpr, *above = row - wpr;
+        const uint32_t cur = row[w], u = above[w];
+        if (!cur)
+            continue;
+        const uint32_t mp = w > 0 ? row[w - 1] : 0u, up = w > 0 ? above[w - 1] : 0u;
+        const uint32_t sm = cur & ~((cur << 1) | (mp >> 31)), su = u & ~((u << 1) | (up >> 31));
+        const uint32_t pm = pre[wi], pu = pre[wi - wc];
+        const uint32_t o = cur & u, op = mp & up;
+        uint32_t os = o & ~((o << 1) | (op >> 31));  // first pixel of every stretch of overlap
+        while (os) {
+            const int bit = __ffs((int)os) - 1;
+            os &= os - 1;
+            const uint32_t le = sil_le(bit);
+            sil_unite(parent, pm + __popc(sm & le) - 1u, pu + __popc(su & le) - 1u);
+        }
+        if (conn8) {
+            const uint32_t mn = w + 1 < wc ? row[w + 1] : 0u, un = w + 1 < wc ? above[w + 1] : 0u;
+            const uint32_t mL = (cur << 1) | (mp >> 31), mR = (cur >> 1) | (mn << 31);
+            const uint32_t uL = (u << 1) | (up >> 31), uR = (u >> 1) | (un << 31);
+            uint32_t dl = cur & ~mL & uL & ~u;  // a run starts here; the row above has the pixel to the left only
+            uint32_t dr = cur & ~mR & uR & ~u;  // a run ends here; the row above has the pixel to the right only
+            while (dl) {
+                const int bit = __ffs((int)dl) - 1;
+                dl &= dl - 1;
+                sil_unite(parent, pm + __popc(sm & sil_le(bit)) - 1u, sil_run_at(m, pre, y - 1, 32 * w + bit - 1, wc, wpr));
+            }
+            while (dr) {
+                const int bit = __ffs((int)dr) - 1;
+                dr &= dr - 1;
+                sil_unite(parent, pm + __popc(sm & sil_le(bit)) - 1u, sil_run_at(m, pre, y - 1, 32 * w + bit + 1, wc, wpr));
+            }
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // every run to its root: pointer jumping, the depth halves per round
+    for (;;) {
+        int changed = 0;
+        for (int r = t; r < R.n; r += FX_BLOCK) {
+            const uint32_t q = ((volatile uint32_t *)parent)[r];
+            const uint32_t g = ((volatile uint32_t *)parent)[q];
+            if (g != q) {
+                parent[r] = g;
+                changed = 1;
+            }
+        }
+        __threadfence_block();
+        if (!__syncthreads_or(changed))
+            break;
+    }
+    return R;
+}
+
+// Calls f(segment bits, run index) for every stretch of set bits of word w of row y.
+template <typename F>
+__device__ __forceinline__ void sil_for_segments(const uint32_t *m, const uint32_t *pre, int y, int w, int wc, int wpr, F f)
+{
+    uint32_t word = m[y * wpr + w];
+    if (!word)
+        return;
+    const uint32_t sm = sil_starts(m + y * wpr, w);
+    const uint32_t pm = pre[y * wc + w];
+    while (word) {
+        const uint32_t low = word & (0u - word);
+        const uint32_t seg = word & ~(word + low);  // the lowest stretch of ones
+        const int bit = __ffs((int)word) - 1;
+        f(seg, pm + __popc(sm & sil_le(bit)) - 1u);
+        word &= ~seg;
+    }
+}
+
 #ifdef SIL_TIMING
 #define SIL_TICK(n)                                        \
     do {                                                   \
@@ -341,8 +755,28 @@ __device__ __forceinline__ uint32_t sil_spread4(uint32_t nib)
 
 enum {
     SV_COUNT = 0, SV_THRESH, SV_INV, SV_MINX, SV_MINY, SV_MAXX, SV_MAXY, SV_CX0, SV_CY0, SV_CW, SV_CH, SV_NW,
-    SV_NH, SV_NRUNS, SV_ANYKEEP, SV_NEAR, SV_N
+    SV_NH, SV_NRUNS, SV_ANYKEEP, SV_NEAR, SV_MAXSZ, SV_N
 };
+
+// Block-wide bounding box: per-thread extremes into s_v[SV_MINX .. SV_MAXY].
+__device__ __forceinline__ void sil_box_reduce(int mnx, int mny, int mxx, int mxy, int *s_v)
+{
+#pragma unroll
+    for (int o = FX_WAVE / 2; o > 0; o >>= 1) {
+        const int a = __shfl_xor(mnx, o, FX_WAVE), b2 = __shfl_xor(mny, o, FX_WAVE);
+        const int c = __shfl_xor(mxx, o, FX_WAVE), d2 = __shfl_xor(mxy, o, FX_WAVE);
+        mnx = a < mnx ? a : mnx;
+        mny = b2 < mny ? b2 : mny;
+        mxx = c > mxx ? c : mxx;
+        mxy = d2 > mxy ? d2 : mxy;
+    }
+    if (fx_lane() == 0 && mxx >= 0) {
+        atomicMin(&s_v[SV_MINX], mnx);
+        atomicMin(&s_v[SV_MINY], mny);
+        atomicMax(&s_v[SV_MAXX], mxx);
+        atomicMax(&s_v[SV_MAXY], mxy);
+    }
+}
 
 __global__ __launch_bounds__(FX_BLOCK) void sil_mask_kernel(SilArgs A)
 {
@@ -351,9 +785,9 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_mask_kernel(SilArgs A)
     __shared__ uint32_t s_hist[256];
     __shared__ uint32_t s_scan[16 + 256];
     __shared__ uint16_t s_xtab[SIL_MAX_SIDE + 32], s_ytab[SIL_MAX_SIDE];
-    __shared__ uint32_t s_parent[SIL_RUNS_LDS], s_size[SIL_RUNS_LDS];
+    __shared__ uint32_t s_runs[2 * SIL_RUNS_LDS];  // parent | per-root value of the labelling in progress
     __shared__ int s_v[SV_N];
-    __shared__ unsigned long long s_best;
+    __shared__ unsigned long long s_best, s_first;
 #ifdef SIL_TIMING
     __shared__ unsigned long long s_tick[24];
 #endif
@@ -373,11 +807,18 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_mask_kernel(SilArgs A)
         s_hist[t] = A.hist[b * 256 + t];
         if (t < SV_N)
             s_v[t] = t == SV_MINX ? W : t == SV_MINY ? H : (t == SV_MAXX || t == SV_MAXY) ? -1 : 0;
-        if (t == 0)
+        if (t == 0) {
             s_best = 0ull;
+            s_first = ~0ull;
+        }
         __syncthreads();
         SIL_TICK(0);
-        {
+        const bool cv = A.mode == FX_SIL_OPENCV;
+        uint32_t *glob_runs = A.runs + (int64_t)blockIdx.x * 2 * A.run_cap;
+        if (cv) {
+            if (t == 0)
+                s_v[SV_THRESH] = A.level[b];  // OpenCV's Otsu level: a serial recurrence, run by sil_otsu_cv_kernel
+        } else {
             // inclusive prefix sums of the counts and of level * count (both below 2^32)
             const int lane = fx_lane(), wave = fx_wave();
             uint32_t wb = s_hist[t], sb = (uint32_t)t * wb;
@@ -518,15 +959,15 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_mask_kernel(SilArgs A)
         __syncthreads();
 
         SIL_TICK(2);
-        // ---- 3x3 closing then opening (reference :170-186)
-        sil_morph<true>(mA, mB, H, W, wpr);
-        sil_morph<false>(mB, mA, H, W, wpr);
-        sil_morph<false>(mA, mB, H, W, wpr);
-        sil_morph<true>(mB, mA, H, W, wpr);
+        if (!cv) {
+            // ---- 3x3 closing then opening (reference :170-186, scipy.ndimage branch)
+            sil_morph<true>(mA, mB, H, W, wpr);
+            sil_morph<false>(mB, mA, H, W, wpr);
+            sil_morph<false>(mA, mB, H, W, wpr);
+            sil_morph<true>(mB, mA, H, W, wpr);
 
-        SIL_TICK(3);
-        // ---- bounding box of the foreground (reference :191-221, branch without cv2)
-        {
+            SIL_TICK(3);
+            // ---- bounding box of the foreground (reference :209-214, branch without cv2)
             int mnx = W, mny = H, mxx = -1, mxy = -1;
             for (int wi = t; wi < H * wcH; wi += FX_BLOCK) {
                 const int y = wi / wcH, w = wi - y * wcH;
@@ -539,21 +980,123 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_mask_kernel(SilArgs A)
                     mxy = y > mxy ? y : mxy;
                 }
             }
-#pragma unroll
-            for (int o = FX_WAVE / 2; o > 0; o >>= 1) {
-                const int a = __shfl_xor(mnx, o, FX_WAVE), b2 = __shfl_xor(mny, o, FX_WAVE);
-                const int c = __shfl_xor(mxx, o, FX_WAVE), d2 = __shfl_xor(mxy, o, FX_WAVE);
-                mnx = a < mnx ? a : mnx;
-                mny = b2 < mny ? b2 : mny;
-                mxx = c > mxx ? c : mxx;
-                mxy = d2 > mxy ? d2 : mxy;
+            sil_box_reduce(mnx, mny, mxx, mxy, s_v);
+        } else {
+            // ---- cv2.morphologyEx with the 5x5 ellipse: close, iterations = 2 (dilate, dilate, erode, erode),
+            // then open (erode, dilate) (reference :171-177)
+            sil_morph_cv<true, true>(mA, mB, H, W, wpr);
+            sil_morph_cv<true, true>(mB, mA, H, W, wpr);
+            sil_morph_cv<false, true>(mA, mB, H, W, wpr);
+            sil_morph_cv<false, true>(mB, mA, H, W, wpr);
+            sil_morph_cv<false, true>(mA, mB, H, W, wpr);
+            sil_morph_cv<true, true>(mB, mA, H, W, wpr);
+
+            SIL_TICK(3);
+            // ---- box of the external contour with the largest contourArea (reference :198-221).
+            // (1) background runs, 4-connected; those that reach the image frame are the outside
+            for (int wi = t; wi < H * wcH; wi += FX_BLOCK) {
+                const int y = wi / wcH, w = wi - y * wcH;
+                mB[y * wpr + w] = ~mA[y * wpr + w] & (w == wcH - 1 ? lastH : ~0u);
             }
-            if (fx_lane() == 0 && mxx >= 0) {
-                atomicMin(&s_v[SV_MINX], mnx);
-                atomicMin(&s_v[SV_MINY], mny);
-                atomicMax(&s_v[SV_MAXX], mxx);
-                atomicMax(&s_v[SV_MAXY], mxy);
+            SilRuns bg = sil_label(mB, H, wcH, wpr, false, pre, s_scan, &s_v[SV_NRUNS], s_runs, glob_runs, A.run_cap);
+            for (int wi = t; wi < H * wcH; wi += FX_BLOCK) {
+                const int y = wi / wcH, w = wi - y * wcH;
+                sil_for_segments(mB, pre, y, w, wcH, wpr, [&](uint32_t seg, uint32_t id) {
+                    const bool frame = y == 0 || y == H - 1 || (w == 0 && (seg & 1u)) ||
+                                       (w == wcH - 1 && ((seg >> ((W - 1) & 31)) & 1u));
+                    if (frame)
+                        bg.val[bg.parent[id]] = 1u;
+                });
             }
+            __threadfence_block();
+            __syncthreads();
+            // (2) holes filled: components nested inside a hole vanish, outer borders stay as they are.  The
+            // complement is taken from mA again because mB is being overwritten.
+            for (int wi = t; wi < H * wcH; wi += FX_BLOCK) {
+                const int y = wi / wcH, w = wi - y * wcH;
+                const uint32_t m = mA[y * wpr + w];
+                uint32_t comp = ~m & (w == wcH - 1 ? lastH : ~0u), holes = 0u;
+                if (comp) {
+                    const uint32_t cp = w > 0 ? ~mA[y * wpr + w - 1] : 0u;
+                    const uint32_t sm = comp & ~((comp << 1) | (cp >> 31));
+                    const uint32_t pm = pre[wi];
+                    while (comp) {
+                        const uint32_t low = comp & (0u - comp);
+                        const uint32_t seg = comp & ~(comp + low);
+                        const int bit = __ffs((int)comp) - 1;
+                        if (!bg.val[bg.parent[pm + __popc(sm & sil_le(bit)) - 1u]])
+                            holes |= seg;
+                        comp &= ~seg;
+                    }
+                }
+                mB[y * wpr + w] = m | holes;
+            }
+            // (3) 8-connected components of the filled mask = the external contours
+            SilRuns fg = sil_label(mB, H, wcH, wpr, true, pre, s_scan, &s_v[SV_NRUNS], s_runs, glob_runs, A.run_cap);
+            // (4) twice the signed area inside each outer border, as a sum over the corners of the pixel grid:
+            // the border follower steps between the two foreground pixels of a straight corner and cuts across
+            // the background pixel of a concave corner; saddle corners give two opposite steps that cancel.
+            const int wcV = (W + 32) >> 5;  // corners x = 0 .. W
+            for (int vi = t; vi < (H + 1) * wcV; vi += FX_BLOCK) {
+                const int vy = vi / wcV, w = vi - vy * wcV;
+                const uint32_t *ru = mB + (vy - 1) * wpr, *rd = mB + vy * wpr;
+                const uint32_t up = vy > 0 && w < wcH ? ru[w] : 0u, upp = vy > 0 && w > 0 ? ru[w - 1] : 0u;
+                const uint32_t dn = vy < H && w < wcH ? rd[w] : 0u, dnp = vy < H && w > 0 ? rd[w - 1] : 0u;
+                const uint32_t ca = (up << 1) | (upp >> 31), cb = up, cc = (dn << 1) | (dnp >> 31), cd = dn;
+                uint32_t act = (ca & cb & ~cc & ~cd) | (cc & cd & ~ca & ~cb) | (ca & cc & ~cb & ~cd) | (cb & cd & ~ca & ~cc) |
+                               (ca & cb & cc & ~cd) | (ca & cb & cd & ~cc) | (ca & cc & cd & ~cb) | (cb & cc & cd & ~ca);
+                while (act) {
+                    const int bit = __ffs((int)act) - 1;
+                    act &= act - 1;
+                    const int vx = 32 * w + bit;
+                    const uint32_t code = ((ca >> bit) & 1u) | (((cb >> bit) & 1u) << 1) | (((cc >> bit) & 1u) << 2) |
+                                          (((cd >> bit) & 1u) << 3);
+                    // pixels around the corner: a = (vx-1, vy-1), b = (vx, vy-1), c = (vx-1, vy), d = (vx, vy)
+                    int px, py, qx, qy;
+                    switch (code) {
+                    case 0x3: px = vx - 1, py = vy - 1, qx = vx, qy = vy - 1; break;      // a -> b
+                    case 0xC: px = vx, py = vy, qx = vx - 1, qy = vy; break;              // d -> c
+                    case 0x5: px = vx - 1, py = vy, qx = vx - 1, qy = vy - 1; break;      // c -> a
+                    case 0xA: px = vx, py = vy - 1, qx = vx, qy = vy; break;              // b -> d
+                    case 0x7: px = vx - 1, py = vy, qx = vx, qy = vy - 1; break;          // c -> b
+                    case 0xB: px = vx - 1, py = vy - 1, qx = vx, qy = vy; break;          // a -> d
+                    case 0xD: px = vx, py = vy, qx = vx - 1, qy = vy - 1; break;          // d -> a
+                    default: px = vx, py = vy - 1, qx = vx - 1, qy = vy; break;           // 0xE: b -> c
+                    }
+                    const uint32_t root = fg.parent[sil_run_at(mB, pre, py, px, wcH, wpr)];
+                    atomicAdd(&fg.val[root], (uint32_t)(px * qy - py * qx));
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+            // (5) the largest area; among equals the contour found last in raster order (cv2.findContours lists
+            // the contours in reverse order of discovery and max() keeps the first)
+            for (int r = t; r < fg.n; r += FX_BLOCK) {
+                if (fg.parent[r] == (uint32_t)r) {
+                    const int a2 = (int)fg.val[r];
+                    atomicMax(&s_best, ((unsigned long long)(uint32_t)(a2 < 0 ? -a2 : a2) << 32) | (unsigned long long)r);
+                }
+            }
+            __syncthreads();
+            int mnx = W, mny = H, mxx = -1, mxy = -1;
+            if (fg.n > 0) {
+                const uint32_t best = (uint32_t)(s_best & 0xFFFFFFFFull);
+                for (int wi = t; wi < H * wcH; wi += FX_BLOCK) {
+                    const int y = wi / wcH, w = wi - y * wcH;
+                    sil_for_segments(mB, pre, y, w, wcH, wpr, [&](uint32_t seg, uint32_t id) {
+                        if (fg.parent[id] != best)
+                            return;
+                        const int lo = 32 * w + __ffs((int)seg) - 1, hi = 32 * w + 31 - __clz((int)seg);
+                        mnx = lo < mnx ? lo : mnx;
+                        mxx = hi > mxx ? hi : mxx;
+                        mny = y < mny ? y : mny;
+                        mxy = y > mxy ? y : mxy;
+                    });
+                }
+            }
+            sil_box_reduce(mnx, mny, mxx, mxy, s_v);
+            if (t == 0)
+                s_best = 0ull;
         }
         __syncthreads();
 
@@ -664,158 +1207,69 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_mask_kernel(SilArgs A)
         __syncthreads();
 
         SIL_TICK(7);
-        // ---- 3x3 opening of the resized mask (reference :246-346)
-        sil_morph<false>(mB, mA, new_h, new_w, wpr);
-        sil_morph<true>(mA, mB, new_h, new_w, wpr);
+        // ---- opening of the resized mask (reference :246-264): 3x3 box, or cv2's 3x3 ellipse (a cross)
+        if (!cv) {
+            sil_morph<false>(mB, mA, new_h, new_w, wpr);
+            sil_morph<true>(mA, mB, new_h, new_w, wpr);
+        } else {
+            sil_morph_cv<false, false>(mB, mA, new_h, new_w, wpr);
+            sil_morph_cv<true, false>(mA, mB, new_h, new_w, wpr);
+        }
 
         SIL_TICK(8);
-        // ---- 4-connected components over row runs
-        // A run is named by the raster-order rank of its first pixel: the run
-        // that holds a set pixel is the latest run started at or before it.
+        // ---- connected components over row runs: 4-connected (scipy.ndimage.label) or 8-connected
+        // (cv2.connectedComponentsWithStats(connectivity=8)), reference :284-311
         const int nwS = new_h * wcS;
-        const int per = (nwS + FX_BLOCK - 1) / FX_BLOCK;
-        {
-            uint32_t local = 0;
-            for (int j = 0; j < per; j++) {
-                const int wi = t * per + j;
-                if (wi < nwS) {
-                    const int y = wi / wcS, w = wi - y * wcS;
-                    const uint32_t m = mB[y * wpr + w];
-                    const uint32_t p = w > 0 ? mB[y * wpr + w - 1] : 0u;
-                    local += __popc(m & ~((m << 1) | (p >> 31)));
-                }
-            }
-            // exclusive prefix over the block: wave scan, then the waves in front
-            uint32_t inc = local;
-#pragma unroll
-            for (int o = 1; o < FX_WAVE; o <<= 1) {
-                const uint32_t u = __shfl_up(inc, o, FX_WAVE);
-                if (fx_lane() >= o)
-                    inc += u;
-            }
-            if (fx_lane() == FX_WAVE - 1)
-                s_scan[fx_wave()] = inc;
-            s_scan[16 + t] = inc - local;
-        }
-        __syncthreads();
-        {
-            uint32_t base = s_scan[16 + t], total = 0;
-#pragma unroll
-            for (int w = 0; w < FX_WAVES_PER_BLOCK; w++) {
-                base += w < fx_wave() ? s_scan[w] : 0u;
-                total += s_scan[w];
-            }
-            for (int j = 0; j < per; j++) {
-                const int wi = t * per + j;
-                if (wi < nwS) {
-                    const int y = wi / wcS, w = wi - y * wcS;
-                    const uint32_t m = mB[y * wpr + w];
-                    const uint32_t p = w > 0 ? mB[y * wpr + w - 1] : 0u;
-                    pre[wi] = base;
-                    base += __popc(m & ~((m << 1) | (p >> 31)));
-                }
-            }
-            if (t == 0)
-                s_v[SV_NRUNS] = (int)total;
-        }
-        __syncthreads();
-        const int nruns = s_v[SV_NRUNS];
-        uint32_t *parent = nruns <= SIL_RUNS_LDS ? s_parent : A.runs + (int64_t)blockIdx.x * 2 * A.run_cap;
-        uint32_t *rsize = nruns <= SIL_RUNS_LDS ? s_size : parent + A.run_cap;
-        for (int r = t; r < nruns; r += FX_BLOCK) {
-            parent[r] = (uint32_t)r;
-            rsize[r] = 0u;
-        }
-        __syncthreads();
-        SIL_TICK(9);
-        // runs of neighbouring rows that share a column belong together
-        for (int wi = t + wcS; wi < nwS; wi += FX_BLOCK) {
-            const int y = wi / wcS, w = wi - y * wcS;
-            const uint32_t m = mB[y * wpr + w], u = mB[(y - 1) * wpr + w];
-            const uint32_t mp = w > 0 ? mB[y * wpr + w - 1] : 0u, up = w > 0 ? mB[(y - 1) * wpr + w - 1] : 0u;
-            const uint32_t o = m & u, op = mp & up;
-            uint32_t os = o & ~((o << 1) | (op >> 31));  // first pixel of every stretch of overlap
-            if (!os)
-                continue;
-            const uint32_t sm = m & ~((m << 1) | (mp >> 31)), su = u & ~((u << 1) | (up >> 31));
-            const uint32_t pm = pre[wi], pu = pre[wi - wcS];
-            while (os) {
-                const int bit = __ffs((int)os) - 1;
-                os &= os - 1;
-                const uint32_t le = sil_le(bit);
-                sil_unite(parent, pm + __popc(sm & le) - 1u, pu + __popc(su & le) - 1u);
-            }
-        }
-        __threadfence_block();
-        __syncthreads();
-        // every run to its root: pointer jumping, the depth halves per round
-        for (;;) {
-            int changed = 0;
-            for (int r = t; r < nruns; r += FX_BLOCK) {
-                const uint32_t q = ((volatile uint32_t *)parent)[r];
-                const uint32_t g = ((volatile uint32_t *)parent)[q];
-                if (g != q) {
-                    parent[r] = g;
-                    changed = 1;
-                }
-            }
-            __threadfence_block();
-            if (!__syncthreads_or(changed))
-                break;
-        }
+        SilRuns cc = sil_label(mB, new_h, wcS, wpr, cv, pre, s_scan, &s_v[SV_NRUNS], s_runs, glob_runs, A.run_cap);
         SIL_TICK(10);
         // component sizes
         for (int wi = t; wi < nwS; wi += FX_BLOCK) {
             const int y = wi / wcS, w = wi - y * wcS;
-            uint32_t m = mB[y * wpr + w];
-            if (!m)
-                continue;
-            const uint32_t mp = w > 0 ? mB[y * wpr + w - 1] : 0u;
-            const uint32_t sm = m & ~((m << 1) | (mp >> 31));
-            const uint32_t pm = pre[wi];
-            while (m) {
-                const uint32_t low = m & (0u - m);
-                const uint32_t seg = m & ~(m + low);  // the lowest stretch of ones
-                const int bit = __ffs((int)m) - 1;
-                const uint32_t id = pm + __popc(sm & sil_le(bit)) - 1u;
-                atomicAdd(&rsize[parent[id]], (uint32_t)__popc(seg));
-                m &= ~seg;
-            }
+            sil_for_segments(mB, pre, y, w, wcS, wpr, [&](uint32_t seg, uint32_t id) {
+                atomicAdd(&cc.val[cc.parent[id]], (uint32_t)__popc(seg));
+            });
         }
         __threadfence_block();
         __syncthreads();
         SIL_TICK(11);
-        // keep components of at least min_size pixels; when none is that large
-        // keep the largest one, the first in raster order among equals
-        for (int r = t; r < nruns; r += FX_BLOCK) {
-            if (parent[r] == (uint32_t)r) {
-                const uint32_t sz = rsize[r];
+        // keep components of at least min_size pixels; when none is that large keep the largest one, among
+        // equals the one with the lowest label: first in raster order for scipy, first in the raster order of
+        // 2x2 blocks for OpenCV (whose labelling scans such blocks)
+        for (int r = t; r < cc.n; r += FX_BLOCK) {
+            if (cc.parent[r] == (uint32_t)r) {
+                const uint32_t sz = cc.val[r];
                 if ((int)sz >= A.min_size)
                     s_v[SV_ANYKEEP] = 1;
-                atomicMax(&s_best, ((unsigned long long)sz << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)r));
+                atomicMax(&s_v[SV_MAXSZ], (int)sz);
             }
         }
         __syncthreads();
         const bool any_keep = s_v[SV_ANYKEEP] != 0;
-        const uint32_t best_root = 0xFFFFFFFFu - (uint32_t)(s_best & 0xFFFFFFFFull);
+        if (!any_keep && cc.n > 0) {
+            const uint32_t maxsz = (uint32_t)s_v[SV_MAXSZ];
+            for (int wi = t; wi < nwS; wi += FX_BLOCK) {
+                const int y = wi / wcS, w = wi - y * wcS;
+                sil_for_segments(mB, pre, y, w, wcS, wpr, [&](uint32_t seg, uint32_t id) {
+                    const uint32_t root = cc.parent[id];
+                    if (cc.val[root] != maxsz)
+                        return;
+                    const uint32_t x = 32u * w + (uint32_t)(__ffs((int)seg) - 1);
+                    const uint32_t key = cv ? (((uint32_t)y >> 1) << 16) | (x >> 1) : root;
+                    atomicMin(&s_first, ((unsigned long long)key << 32) | (unsigned long long)root);
+                });
+            }
+            __syncthreads();
+        }
+        const uint32_t best_root = (uint32_t)(s_first & 0xFFFFFFFFull);
         // kept pixels into mA
         for (int wi = t; wi < nwS; wi += FX_BLOCK) {
             const int y = wi / wcS, w = wi - y * wcS;
-            uint32_t m = mB[y * wpr + w], kept = 0u;
-            if (m) {
-                const uint32_t mp = w > 0 ? mB[y * wpr + w - 1] : 0u;
-                const uint32_t sm = m & ~((m << 1) | (mp >> 31));
-                const uint32_t pm = pre[wi];
-                while (m) {
-                    const uint32_t low = m & (0u - m);
-                    const uint32_t seg = m & ~(m + low);
-                    const int bit = __ffs((int)m) - 1;
-                    const uint32_t root = parent[pm + __popc(sm & sil_le(bit)) - 1u];
-                    const bool keep = any_keep ? (int)rsize[root] >= A.min_size : root == best_root;
-                    kept |= keep ? seg : 0u;
-                    m &= ~seg;
-                }
-            }
+            uint32_t kept = 0u;
+            sil_for_segments(mB, pre, y, w, wcS, wpr, [&](uint32_t seg, uint32_t id) {
+                const uint32_t root = cc.parent[id];
+                const bool keep = any_keep ? (int)cc.val[root] >= A.min_size : root == best_root;
+                kept |= keep ? seg : 0u;
+            });
             mA[y * wpr + w] = kept;
         }
         __syncthreads();
@@ -882,9 +1336,11 @@ inline size_t sil_align(size_t v) { return (v + 255) & ~(size_t)255; }
 
 extern "C" int fx_silhouette_batch_u8(const uint8_t *d_img, int64_t B, int H, int W, int64_t pitch, int64_t stride,
                                       int resolution, double crop_margin, int preprocess_crop, int min_size,
-                                      uint8_t *d_mask, int32_t *d_info, void *stream_)
+                                      int mode, uint8_t *d_mask, int32_t *d_info, void *stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
+    FX_REQUIRE(mode == FX_SIL_PIL || mode == FX_SIL_OPENCV, "fx_silhouette_batch_u8: mode %d (0 = PIL/scipy branch, "
+               "1 = OpenCV branch)", mode);
     FX_REQUIRE(B >= 0, "fx_silhouette_batch_u8: B = %lld", (long long)B);
     if (B == 0)
         return FX_OK;
@@ -910,7 +1366,8 @@ extern "C" int fx_silhouette_batch_u8(const uint8_t *d_img, int64_t B, int H, in
     const int rows = H > resolution ? H : resolution;
     const int side = W > resolution ? W : resolution;
     const int wpr = (side + 31) / 32;
-    const int run_cap = resolution * (resolution / 2 + 1);
+    // most runs a labelling can meet: the resized mask, and for the OpenCV branch also the view itself
+    const int run_cap = mode == FX_SIL_OPENCV ? rows * (side / 2 + 1) : resolution * (resolution / 2 + 1);
     const size_t mask_lds = (size_t)3 * rows * wpr * sizeof(uint32_t);
     // The mask kernel's blocks loop over images: a grid larger than what the device holds at once
     // would run its surplus blocks after the others, on a half-empty device.
@@ -929,8 +1386,9 @@ extern "C" int fx_silhouette_batch_u8(const uint8_t *d_img, int64_t B, int H, in
     const size_t hist_bytes = sil_align((size_t)chunk * 256 * sizeof(uint32_t));
     const int64_t run_blocks = chunk < grid ? chunk : grid;  // blocks a launch really has
     const size_t runs_bytes = sil_align((size_t)run_blocks * 2 * run_cap * sizeof(uint32_t));
+    const size_t level_bytes = sil_align((size_t)chunk * sizeof(int32_t));
     FxCallGuard guard(stream);
-    unsigned char *base = (unsigned char *)guard.scratch(blur_bytes + hist_bytes + runs_bytes, 3);
+    unsigned char *base = (unsigned char *)guard.scratch(blur_bytes + hist_bytes + runs_bytes + level_bytes, 3);
     if (!base)
         return FX_ENOMEM;
 
@@ -949,6 +1407,8 @@ extern "C" int fx_silhouette_batch_u8(const uint8_t *d_img, int64_t B, int H, in
     A.run_cap = run_cap;
     A.wpr = wpr;
     A.rows = rows;
+    A.mode = mode;
+    A.level = (int32_t *)(base + blur_bytes + hist_bytes + runs_bytes);
 
     const bool aligned = (W % 16 == 0) && (pitch % 16 == 0) && (stride % 16 == 0) && (((uintptr_t)d_img) % 16 == 0);
     const int Wp = (W + 15) & ~15;
@@ -957,10 +1417,11 @@ extern "C" int fx_silhouette_batch_u8(const uint8_t *d_img, int64_t B, int H, in
     {
         const int cpr = Wp / 16;
         long best = -1;
-        for (int cand = 16; cand <= SIL_MAX_TROWS - 2 * SIL_HALO; cand++) {
+        const int halo = mode == FX_SIL_OPENCV ? SIL_CV_HALO : SIL_HALO;
+        for (int cand = 16; cand <= SIL_MAX_TROWS - 2 * halo; cand++) {
             const long tiles = (H + cand - 1) / cand;
-            const long rounds = ((long)(cand + 2 * SIL_HALO) * cpr + FX_BLOCK - 1) / FX_BLOCK;
-            const long cost = tiles * rounds * 1000 + tiles * (cand + 2 * SIL_HALO);
+            const long rounds = ((long)(cand + 2 * halo) * cpr + FX_BLOCK - 1) / FX_BLOCK;
+            const long cost = tiles * rounds * 1000 + tiles * (cand + 2 * halo);
             if (best < 0 || cost < best) {
                 best = cost;
                 tr = cand;
@@ -968,7 +1429,19 @@ extern "C" int fx_silhouette_batch_u8(const uint8_t *d_img, int64_t B, int H, in
         }
     }
     A.tr = tr;
-    const size_t blur_lds = (size_t)(tr + 2 * SIL_HALO) * Wp + 256 * sizeof(uint32_t);
+    const size_t blur_lds = mode == FX_SIL_OPENCV ? (size_t)(tr + 2 * SIL_CV_HALO) * Wp * 2 + 256 * sizeof(uint32_t)
+                                                  : (size_t)(tr + 2 * SIL_HALO) * Wp + 256 * sizeof(uint32_t);
+    const size_t otsu_lds = (size_t)FX_WAVE * SIL_OTSU_PITCH * sizeof(uint32_t);
+    if (mode == FX_SIL_OPENCV) {
+        if (blur_lds > 48 * 1024) {
+            FX_HIP_CHECK(hipFuncSetAttribute((const void *)sil_blur_cv_kernel<true>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)blur_lds));
+            FX_HIP_CHECK(hipFuncSetAttribute((const void *)sil_blur_cv_kernel<false>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)blur_lds));
+        }
+        FX_HIP_CHECK(hipFuncSetAttribute((const void *)sil_otsu_cv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)otsu_lds));
+    }
     if (mask_lds > 48 * 1024)  // beyond the default limit of dynamic LDS; set per call: the current device may differ
         FX_HIP_CHECK(hipFuncSetAttribute((const void *)sil_mask_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)mask_lds));
@@ -981,10 +1454,18 @@ extern "C" int fx_silhouette_batch_u8(const uint8_t *d_img, int64_t B, int H, in
         A.info = d_info ? d_info + b0 * 8 : nullptr;
         FX_HIP_CHECK(hipMemsetAsync(A.hist, 0, (size_t)nb * 256 * sizeof(uint32_t), stream));
         const dim3 bgrid((unsigned)((H + tr - 1) / tr), (unsigned)nb);
-        if (aligned)
+        if (mode == FX_SIL_OPENCV) {
+            if (aligned)
+                hipLaunchKernelGGL(sil_blur_cv_kernel<true>, bgrid, dim3(FX_BLOCK), blur_lds, stream, A);
+            else
+                hipLaunchKernelGGL(sil_blur_cv_kernel<false>, bgrid, dim3(FX_BLOCK), blur_lds, stream, A);
+            hipLaunchKernelGGL(sil_otsu_cv_kernel, dim3((unsigned)((nb + FX_WAVE - 1) / FX_WAVE)), dim3(FX_WAVE), otsu_lds,
+                               stream, (const uint32_t *)A.hist, nb, 1.0 / (double)((int64_t)W * H), A.level);
+        } else if (aligned) {
             hipLaunchKernelGGL(sil_blur_kernel<true>, bgrid, dim3(FX_BLOCK), blur_lds, stream, A);
-        else
+        } else {
             hipLaunchKernelGGL(sil_blur_kernel<false>, bgrid, dim3(FX_BLOCK), blur_lds, stream, A);
+        }
         FX_HIP_CHECK(hipGetLastError());
         const int g = (int)(nb < grid ? nb : grid);  // persistent blocks: as many as are resident at once
         {

@@ -132,12 +132,20 @@ def hu_from_partial(partial: torch.Tensor, *, moments: bool = False, hu: bool = 
     return out
 
 
+SIL_BACKENDS = {"pil": 0, "opencv": 1}   # FX_SIL_PIL, FX_SIL_OPENCV
+
+
 def silhouette_batch(images: torch.Tensor, resolution: int = 224, crop_margin: float = 0.05,
-                     preprocess_crop: bool = True, min_size: int = -1, *, info: bool = False) -> dict:
+                     preprocess_crop: bool = True, min_size: int = -1, *, info: bool = False,
+                     backend: str = "opencv") -> dict:
     """Cleaned 0/255 silhouettes [B, resolution, resolution] of a batch of gray
     uint8 views [B, H, W] (Gaussian blur, Otsu, morphology, crop, nearest
     resize, component filter).  With info=True also "info" int32 [B, 8]:
-    Otsu level, inverted flag, crop x0 y0 x1 y1, resized width and height."""
+    Otsu level, inverted flag, crop x0 y0 x1 y1, resized width and height.
+    `backend` names the branch of the reference that is reproduced: "opencv"
+    (the one its production run took) or "pil" (the one without OpenCV)."""
+    if backend not in SIL_BACKENDS:
+        raise ValueError(f"backend must be 'opencv' or 'pil', got {backend!r}")
     _require_cuda(images, "images")
     if images.dtype != torch.uint8 or images.dim() != 3:
         raise ValueError(f"images must be uint8 [B, H, W], got {images.dtype} {tuple(images.shape)}")
@@ -154,7 +162,8 @@ def silhouette_batch(images: torch.Tensor, resolution: int = 224, crop_margin: f
     pitch = images.stride(1) if H > 1 else W
     stride = images.stride(0) if B > 1 else pitch * H
     _lib.call("fx_silhouette_batch_u8", images.data_ptr(), B, H, W, pitch, stride, res, float(crop_margin),
-              int(bool(preprocess_crop)), int(min_size), out["mask"].data_ptr(), _ptr(out.get("info")), stream)
+              int(bool(preprocess_crop)), int(min_size), SIL_BACKENDS[backend], out["mask"].data_ptr(),
+              _ptr(out.get("info")), stream)
     return out
 
 

@@ -8,10 +8,14 @@ of the per-sample mean/std (:641-644) runs in the HIP kernels of libfx
 
 The silhouette preprocessing in front of it (:101-440: blur, Otsu, morphology,
 bounding-box crop, nearest resize, mask cleaning) runs on the device as well
-(csrc/fx_sil.hip) and follows the code path the reference itself takes when
-OpenCV is not installed (PIL + scipy.ndimage), which is the only one of its two
-paths that can be run and checked in an environment without cv2.  Only the
-image decoding is a PIL call on the host.
+(csrc/fx_sil.hip).  The reference has two code paths there, chosen by whether
+OpenCV is installed; both are built.  SILHOUETTE_BACKEND = "opencv" (the
+default: the path its production run took, cv2.GaussianBlur / THRESH_OTSU /
+5x5 ellipse morphology / largest external contour / 8-connected component
+filter) or "pil" (PIL + scipy.ndimage); the `silhouette_backend` key of a
+task's config, the `backend` argument of the functions below and the
+--silhouette_backend flag override it.  Only the image decoding is a PIL call
+on the host.
 
 Added next to the reference API: `compute_hu_batch` and `process_samples`,
 which push many views through one kernel launch.
@@ -29,6 +33,8 @@ import numpy as np
 from PIL import Image
 
 logger = logging.getLogger("extract_2d_hu")
+
+SILHOUETTE_BACKEND = "opencv"   # which branch of the reference's preprocessing is reproduced: "opencv" or "pil"
 
 IMAGE_SUFFIXES = (".png", ".jpg", ".jpeg")
 HU_COLS = ["id"] + [f"hu{i + 1}_mean" for i in range(7)] + [f"hu{i + 1}_std" for i in range(7)] + ["note"]
@@ -81,12 +87,13 @@ def pad_and_resize(img: np.ndarray, target: int, bg_color: str) -> np.ndarray:
     return out[0].cpu().numpy()
 
 
-def compute_silhouettes(images: np.ndarray, resolution: int, crop_margin: float, preprocess_crop: bool):
+def compute_silhouettes(images: np.ndarray, resolution: int, crop_margin: float, preprocess_crop: bool,
+                        backend: Optional[str] = None):
     """Cleaned 0/255 silhouettes of equally sized gray views [B, H, W] in one
     device call: (uint8 [B, res, res], int32 [B, 8] = Otsu level, inverted
     flag, crop x0 y0 x1 y1, resized width and height).  Covers compute_otsu,
     find_largest_bbox, the mask half of preprocess_image and clean_mask_np of
-    the reference (:129-440, branch without OpenCV)."""
+    the reference (:129-440) on the chosen branch."""
     import torch
     from . import engine
 
@@ -94,12 +101,12 @@ def compute_silhouettes(images: np.ndarray, resolution: int, crop_margin: float,
     if arr.ndim == 2:
         arr = arr[None]
     out = engine.silhouette_batch(torch.from_numpy(arr).to(_device()), resolution, crop_margin, preprocess_crop,
-                                  info=True)
+                                  info=True, backend=backend or SILHOUETTE_BACKEND)
     return out["mask"].cpu().numpy(), out["info"].cpu().numpy()
 
 
 def preprocess_image(img: np.ndarray, resolution: int, crop_margin: float, bg_color: str,
-                     preprocess_crop: bool) -> Tuple[np.ndarray, np.ndarray]:
+                     preprocess_crop: bool, backend: Optional[str] = None) -> Tuple[np.ndarray, np.ndarray]:
     """(preprocessed gray image, cleaned 0/255 silhouette), both
     resolution x resolution uint8 (reference :352-440), both from the device."""
     import torch
@@ -107,7 +114,8 @@ def preprocess_image(img: np.ndarray, resolution: int, crop_margin: float, bg_co
 
     assert img.ndim == 2
     d = torch.from_numpy(np.ascontiguousarray(img, dtype=np.uint8)[None]).to(_device())
-    sil = engine.silhouette_batch(d, resolution, crop_margin, preprocess_crop, info=True)
+    sil = engine.silhouette_batch(d, resolution, crop_margin, preprocess_crop, info=True,
+                                  backend=backend or SILHOUETTE_BACKEND)
     pre = engine.gray_fit_batch(d, sil["info"], resolution, 255 if bg_color == "white" else 0)
     return pre[0].cpu().numpy(), sil["mask"][0].cpu().numpy()
 
@@ -146,7 +154,7 @@ def compute_hu_from_image(img_or_mask: np.ndarray) -> np.ndarray:
 def hu_from_clouds_device(points, offsets, views: int = 12, resolution: int = 224, point_size: float = 2.0,
                           crop_margin: float = 0.05, preprocess_crop: bool = False, use_silhouette: bool = False,
                           bg_color: str = "white", camera_radius_factor: float = 2.0, seed: int = 42,
-                          return_views: bool = False):
+                          return_views: bool = False, backend: Optional[str] = None):
     """hu_from_clouds for clouds already in HBM (float32 [total, 3], int64
     offsets [B + 1]); returns a float32 device tensor [B, 14]."""
     import torch
@@ -155,7 +163,8 @@ def hu_from_clouds_device(points, offsets, views: int = 12, resolution: int = 22
                                                 camera_radius_factor, seed)
     B = rendered.shape[0]
     raw = rendered.reshape(B * views, resolution, resolution)
-    sil = engine.silhouette_batch(raw, resolution, crop_margin, preprocess_crop, info=not use_silhouette)
+    sil = engine.silhouette_batch(raw, resolution, crop_margin, preprocess_crop, info=not use_silhouette,
+                                  backend=backend or SILHOUETTE_BACKEND)
     target = sil["mask"] if use_silhouette else engine.gray_fit_batch(raw, sil["info"], resolution,
                                                                       255 if bg_color == "white" else 0)
     rows = engine.hu_batch(target)["hulog7"]
@@ -167,7 +176,7 @@ def hu_from_clouds_device(points, offsets, views: int = 12, resolution: int = 22
 def hu_from_clouds(clouds: Sequence[np.ndarray], views: int = 12, resolution: int = 224, point_size: float = 2.0,
                    crop_margin: float = 0.05, preprocess_crop: bool = False, use_silhouette: bool = False,
                    bg_color: str = "white", camera_radius_factor: float = 2.0, seed: int = 42,
-                   return_views: bool = False):
+                   return_views: bool = False, backend: Optional[str] = None):
     """Sampled clouds -> rendered views -> preprocessing -> log-Hu -> per-sample
     mean / std, float32 [B, 14], without the views leaving the device: the
     chain of the reference's render_views.py (its matplotlib renderer) and
@@ -179,7 +188,7 @@ def hu_from_clouds(clouds: Sequence[np.ndarray], views: int = 12, resolution: in
             raise ValueError("empty point cloud")
     pts, off = render_views.pack_clouds(clouds, _device())
     res = hu_from_clouds_device(pts, off, views, resolution, point_size, crop_margin, preprocess_crop, use_silhouette,
-                                bg_color, camera_radius_factor, seed, return_views)
+                                bg_color, camera_radius_factor, seed, return_views, backend)
     if return_views:
         return res[0].cpu().numpy().astype(np.float32), res[1]
     return res.cpu().numpy().astype(np.float32)
@@ -249,7 +258,8 @@ def decode_samples(tasks: Iterable[Tuple[str, str, Dict[str, Any]]], workers: Op
     def key_of(k: int, shape) -> tuple:
         config = tasks[k][2]
         return (tuple(shape), int(config["resolution"]), float(config["crop_margin"]),
-                bool(config["preprocess_crop"]), bool(config["use_silhouette"]), str(config["bg_color"]))
+                bool(config["preprocess_crop"]), bool(config["use_silhouette"]), str(config["bg_color"]),
+                str(config.get("silhouette_backend") or SILHOUETTE_BACKEND))
 
     # native batch decode of the PNG files that share the first PNG's size
     png = [j for j, (_, v) in enumerate(jobs) if v.suffix.lower() == ".png"]
@@ -285,6 +295,7 @@ def decode_samples(tasks: Iterable[Tuple[str, str, Dict[str, Any]]], workers: Op
     in_block = [j for j in range(len(jobs)) if native_ok[j]]
     block_owners = [jobs[j][0] for j in in_block]
     return {"tasks": tasks, "results": results, "views": views, "owners": owners, "keys": keys, "seq": seq,
+            "paths": [str(v) for _, v in jobs],
             "workers": workers, "block": block, "block_owner_tensor": owner,
             "block_rows": [row_of[j] for j in in_block], "block_owners": block_owners,
             "block_keys": [key_of(k, size) for k in block_owners], "block_seq": in_block}
@@ -311,13 +322,15 @@ def finish_samples(decoded: Dict[str, Any]) -> List[Dict[str, Any]]:
             rank = np.empty(len(order), dtype=np.int64)
             rank[order] = np.arange(len(order))
             rows_all = torch.zeros((len(order), 7), dtype=torch.float32, device=dev)
+            usable = np.ones(len(order), dtype=bool)     # per row of rows_all: its view went through
             d_block = None
             nb = len(b_rows)
             # one pass per distinct (view size, settings): normally a single one
             for key in sorted(set(keys) | set(b_keys)):
                 idx = [i for i, kk in enumerate(keys) if kk == key]
                 bidx = [i for i, kk in enumerate(b_keys) if kk == key]
-                _, resolution, crop_margin, preprocess_crop, use_silhouette, bg_color = key
+                _, resolution, crop_margin, preprocess_crop, use_silhouette, bg_color, backend = key
+                where = rank[np.asarray(bidx + [nb + i for i in idx], dtype=np.int64)]
                 try:
                     parts = []
                     if bidx:
@@ -330,17 +343,23 @@ def finish_samples(decoded: Dict[str, Any]) -> List[Dict[str, Any]]:
                         parts.append(ingest.stack_to_device([views[i] for i in idx], dev, decoded["workers"]))
                     raw = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
                     sil = engine.silhouette_batch(raw, resolution, crop_margin, preprocess_crop,
-                                                  info=not use_silhouette)
+                                                  info=not use_silhouette, backend=backend)
                     if use_silhouette:
                         target = sil["mask"]
                     else:
                         target = engine.gray_fit_batch(raw, sil["info"], resolution, 255 if bg_color == "white" else 0)
-                    where = rank[np.asarray(bidx + [nb + i for i in idx], dtype=np.int64)]
                     rows_all[torch.from_numpy(where).to(dev)] = engine.hu_batch(target)["hulog7"]
                 except Exception as e:
-                    for k in {b_owners[i] for i in bidx} | {owners[i] for i in idx}:
-                        results[k]["note"] = f"failed: {e}"
-            uniq, counts = np.unique(all_own[order], return_counts=True)   # owners ascend along the order
+                    # the reference logs a view that fails and goes on with the sample's other views (:629-636)
+                    usable[where] = False
+                    for j in [decoded["block_seq"][i] for i in bidx] + [decoded["seq"][i] for i in idx]:
+                        k = all_own[np.nonzero(all_seq == j)[0][0]]
+                        _log_error(Path(tasks[k][2].get("reports_dir", "reports")), decoded["paths"][j],
+                                   type(e).__name__, e)
+            kept = np.nonzero(usable)[0]
+            if len(kept) < len(order):
+                rows_all = rows_all[torch.from_numpy(kept).to(dev)].contiguous()
+            uniq, counts = np.unique(all_own[order][kept], return_counts=True)   # owners ascend along the order
             off = np.zeros(len(counts) + 1, dtype=np.int64)
             np.cumsum(counts, out=off[1:])
             stats = engine.hu_groupstat(rows_all, torch.from_numpy(off).to(dev)).cpu().numpy()
@@ -424,6 +443,8 @@ def parse_args(argv=None):
     p.add_argument("--overwrite", action="store_true")
     p.add_argument("--reports_dir", type=str, default="../../reports")
     p.add_argument("--batch_samples", type=int, default=512, help="samples per device batch")
+    p.add_argument("--silhouette_backend", type=str, default=None, choices=["opencv", "pil"],
+                   help="branch of the reference's preprocessing to reproduce (default: opencv, its production path)")
     p.add_argument("--seed", type=int, default=42)
     p.add_argument("--verbose", action="store_true")
     return p.parse_args(argv)
@@ -450,7 +471,8 @@ def main(argv=None) -> int:
     config = {"out_dir": str(out_dir), "resolution": int(args.resolution), "use_silhouette": bool(args.use_silhouette),
               "preprocess_crop": bool(args.preprocess_crop), "crop_margin": float(args.crop_margin),
               "bg_color": args.bg_color, "expected_views": int(args.expected_views),
-              "overwrite": bool(args.overwrite), "reports_dir": str(reports_dir)}
+              "overwrite": bool(args.overwrite), "reports_dir": str(reports_dir),
+              "silhouette_backend": args.silhouette_backend or SILHOUETTE_BACKEND}
     tasks = [(sid, str(d), config) for sid, d in ids]
     results: List[Dict[str, Any]] = []
     step = max(1, int(args.batch_samples))

@@ -175,31 +175,42 @@ int fx_hu_from_partial(const int64_t *d_partial, int64_t B, double *d_moments24,
 
 /*
  * Silhouette preprocessing of B gray views H x W (both <= 512), the step the
- * reference runs in front of the Hu moments, on the branch it takes when
- * OpenCV is not installed.  Replaces, per view,
- *   compute_otsu        src/features/extract_2d_hu.py:129-188  (PIL
- *                       GaussianBlur(radius=1), Otsu level :101-126, inversion
- *                       when the foreground exceeds half of the view,
- *                       scipy.ndimage 3x3 closing then opening)
- *   find_largest_bbox   :191-221  (bounding box of the non-zero pixels)
+ * reference runs in front of the Hu moments.  Replaces, per view,
+ *   compute_otsu        src/features/extract_2d_hu.py:129-188
+ *   find_largest_bbox   :191-221
  *   preprocess_image    :352-440  (crop by the box + crop_margin, or the whole
  *                       view when preprocess_crop == 0; PIL nearest resize to
  *                       fit resolution x resolution; centred paste)
- *   clean_mask_np       :246-346  (3x3 opening, 4-connected components below
- *                       min_size pixels dropped, the largest kept when none
- *                       reaches it; min_size < 0 selects the reference default
+ *   clean_mask_np       :246-346  (opening, components below min_size pixels
+ *                       dropped, the largest kept when none reaches it;
+ *                       min_size < 0 selects the reference default
  *                       max(8, int(0.001 * resolution^2)))
  * and writes the cleaned 0/255 silhouette d_mask [B, resolution, resolution],
  * bit-identical to the reference's second return value of preprocess_image.
+ * The reference has two branches, chosen by whether OpenCV is installed;
+ * `mode` selects which one is reproduced:
+ *   FX_SIL_OPENCV  the branch its production run took: cv2.GaussianBlur(5x5,
+ *                  sigma 0) :139, cv2.threshold(THRESH_OTSU) :143, inversion
+ *                  above half foreground :166-168, cv2.morphologyEx with the
+ *                  5x5 MORPH_ELLIPSE, close x2 then open :173-175,
+ *                  cv2.findContours(RETR_EXTERNAL) -> largest cv2.contourArea
+ *                  -> cv2.boundingRect :200-221, 3x3 ellipse opening :262-263,
+ *                  cv2.connectedComponentsWithStats(connectivity=8) :285-297;
+ *   FX_SIL_PIL     the branch without OpenCV: PIL GaussianBlur(radius=1) :154,
+ *                  NumPy Otsu :101-126, scipy.ndimage 3x3 closing / opening
+ *                  :181-183, box of all non-zero pixels :209-214, 3x3 opening
+ *                  :266, 4-connected scipy.ndimage.label :299-311.
  * crop_margin <= 1 is a fraction of the longer box side, > 1 is in pixels.
  * d_info (optional) int32 [B, 8]: Otsu level, 1 if the mask was inverted, crop
  * rectangle x0, y0, x1, y1 (exclusive ends), resized width and height.
  * The gray output of preprocess_image (PIL bicubic fit) is not produced here.
  */
+#define FX_SIL_PIL 0
+#define FX_SIL_OPENCV 1
 int fx_silhouette_batch_u8(const uint8_t *d_img, int64_t B, int H, int W,
                            int64_t pitch, int64_t stride, int resolution,
                            double crop_margin, int preprocess_crop, int min_size,
-                           uint8_t *d_mask, int32_t *d_info, void *stream);
+                           int mode, uint8_t *d_mask, int32_t *d_info, void *stream);
 
 /*
  * Gray half of preprocess_image: pad_and_resize, src/features/extract_2d_hu.py

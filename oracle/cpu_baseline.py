@@ -40,7 +40,7 @@ def run(job):
             rows = []
             for pose in cpu_ref.compute_camera_poses(12, mins, maxs, cen):
                 view = cpu_ref.render_view(p64, pose, 224, stamp)
-                pre, _ = cpu_ref.preprocess_image(view, 224, 0.05, "white", False)
+                pre, _ = cpu_ref.preprocess_image_cv(view, 224, 0.05, "white", False)
                 rows.append(c.hu_batch(pre[None])["hulog7"][0])
             rows = np.stack(rows).astype(np.float32)
             np.concatenate([rows.mean(axis=0), rows.std(axis=0)])
@@ -49,7 +49,7 @@ def run(job):
             c.hu_batch(img[None], thresh=127, on_value=255)
     elif kind == "sil+hu":
         for img in data:
-            mask, _ = cpu_ref.silhouette(img, 224, 0.05, True)
+            mask, _ = cpu_ref.silhouette_cv(img, 224, 0.05, True)
             c.hu_batch(mask[None])
     else:
         for img in data:

@@ -20,7 +20,7 @@ def test_header_symbols_are_exported():
     for n in names:
         assert hasattr(handle, n), f"libfx.so lacks {n}"
     assert sorted(lib.SIGNATURES) == names, "the ctypes table and the header disagree"
-    assert handle.fx_abi_version() == 1
+    assert handle.fx_abi_version() == 2
 
 
 def test_argument_checks_run_without_a_device():

@@ -42,7 +42,7 @@ def test_hu_directory_run(gpu, tmp_path, oracle, c_oracle, hu_panels):
     log = (rep / "read_errors.log").read_text()
     assert "view_09.png" in log and "broken" in log
     for s, sid in enumerate(ids):
-        masks = [oracle.preprocess_image(hu_panels["raw_views"][s, v], 224, 0.05, "white", True)[1] for v in range(3)]
+        masks = [oracle.preprocess_image_cv(hu_panels["raw_views"][s, v], 224, 0.05, "white", True)[1] for v in range(3)]
         rows = c_oracle.hu_batch(np.stack(masks))["hulog7"]
         want = oracle.hu_groupstat(rows)[0]
         got = df.loc[sid, hu.HU_COLS[1:15]].to_numpy(dtype=np.float64).astype(np.float32)
@@ -132,7 +132,7 @@ def test_hu_directory_run_mixed_files(gpu, tmp_path, oracle, c_oracle, hu_panels
             rows = []
             for f in sorted(folder.iterdir()):
                 img = np.asarray(Image.open(f).convert("L"))
-                pre, mask = oracle.preprocess_image(img, 224, 0.05, "white", True)
+                pre, mask = oracle.preprocess_image_cv(img, 224, 0.05, "white", True)
                 rows.append(c_oracle.hu_batch((mask if silhouette else pre)[None])["hulog7"][0])
             want = oracle.hu_groupstat(np.stack(rows))[0]
             got = df.loc[sid, hu.HU_COLS[1:15]].to_numpy(dtype=np.float64).astype(np.float32)
@@ -197,7 +197,7 @@ def test_clouds_to_hu_table_on_the_device(gpu, oracle, c_oracle, tmp_path):
             for v in range(views):
                 img = oracle.render_view(p64, poses[v], res, rv.marker_stamp(2.0))
                 np.testing.assert_array_equal(rendered[b, v].cpu().numpy(), img)
-                pre, mask = oracle.preprocess_image(img, res, 0.05, "white", crop)
+                pre, mask = oracle.preprocess_image_cv(img, res, 0.05, "white", crop)
                 rows.append(c_oracle.hu_batch((mask if use_sil else pre)[None], thresh=-1)["hulog7"][0])
             rows = np.stack(rows).astype(np.float32)
             want = np.concatenate([rows.mean(axis=0), rows.std(axis=0)]).astype(np.float32)

@@ -105,19 +105,20 @@ def test_silhouette_and_gray_fit_random_views(gpu, oracle):
             views.append(np.clip(np.rint(img if k % 2 else 255 - img), 0, 255).astype(np.uint8))
         views = np.stack(views)
         d = torch.from_numpy(views).to(gpu)
-        out = eng.silhouette_batch(d, res, margin, crop, info=True)
-        masks, info = out["mask"].cpu().numpy(), out["info"].cpu().numpy()
-        fit = eng.gray_fit_batch(d, out["info"], res, 255).cpu().numpy()
-        for k in range(3):
-            tag = f"case {case}/{k}: {h}x{w} -> {res}, margin {margin}, crop {crop}"
-            want, winfo = oracle.silhouette(views[k], res, margin, crop)
-            np.testing.assert_array_equal(info[k], winfo, err_msg=tag)
-            np.testing.assert_array_equal(masks[k], want, err_msg=tag)
-            x0, y0, x1, y1 = (int(v) for v in winfo[2:6])
-            cw, ch = x1 - x0, y1 - y0
-            if min(cw / ch, ch / cw) * res >= 0.5:      # PIL refuses a zero-sized target
-                np.testing.assert_array_equal(fit[k], oracle.pad_and_resize(views[k][y0:y1, x0:x1], res, "white"),
-                                              err_msg=tag)
+        for backend, ref in (("pil", oracle.silhouette), ("opencv", oracle.silhouette_cv)):
+            out = eng.silhouette_batch(d, res, margin, crop, info=True, backend=backend)
+            masks, info = out["mask"].cpu().numpy(), out["info"].cpu().numpy()
+            fit = eng.gray_fit_batch(d, out["info"], res, 255).cpu().numpy()
+            for k in range(3):
+                tag = f"case {case}/{k} ({backend}): {h}x{w} -> {res}, margin {margin}, crop {crop}"
+                want, winfo = ref(views[k], res, margin, crop)
+                np.testing.assert_array_equal(info[k], winfo, err_msg=tag)
+                np.testing.assert_array_equal(masks[k], want, err_msg=tag)
+                x0, y0, x1, y1 = (int(v) for v in winfo[2:6])
+                cw, ch = x1 - x0, y1 - y0
+                if min(cw / ch, ch / cw) * res >= 0.5:      # PIL refuses a zero-sized target
+                    np.testing.assert_array_equal(fit[k], oracle.pad_and_resize(views[k][y0:y1, x0:x1], res, "white"),
+                                                  err_msg=tag)
 
 
 def test_center_scale_and_fps_random_clouds(gpu, oracle):

@@ -1,5 +1,7 @@
-"""Silhouette preprocessing on the device against the reference's outputs
-(golden) and against the oracle's PIL + scipy restatement: bit-exact."""
+"""Silhouette preprocessing on the device, both branches of the reference
+(with and without OpenCV), against the reference's own outputs (golden
+fixtures: the committed production panels for the OpenCV branch, outputs of
+the imported reference for the other) and against the oracle: bit-exact."""
 import numpy as np
 import pytest
 import torch
@@ -9,10 +11,25 @@ from conftest import GOLDEN, pkg
 pytestmark = pytest.mark.gpu
 
 
+BACKEND = "pil"   # set per test by the `backend` fixture
+
+
+@pytest.fixture(params=["pil", "opencv"])
+def backend(request):
+    global BACKEND
+    BACKEND = request.param
+    yield request.param
+    BACKEND = "pil"
+
+
+def oracle_silhouette(oracle, *a):
+    return (oracle.silhouette_cv if BACKEND == "opencv" else oracle.silhouette)(*a)
+
+
 def run(gpu, imgs, res=224, margin=0.05, crop=True, min_size=-1):
     eng = pkg("engine")
     out = eng.silhouette_batch(torch.from_numpy(np.ascontiguousarray(imgs)).to(gpu), res, margin, crop, min_size,
-                               info=True)
+                               info=True, backend=BACKEND)
     torch.cuda.synchronize()
     return out["mask"].cpu().numpy(), out["info"].cpu().numpy()
 
@@ -21,7 +38,7 @@ def check(gpu, oracle, imgs, res=224, margin=0.05, crop=True, min_size=-1):
     masks, info = run(gpu, imgs, res, margin, crop, min_size)
     assert masks.shape == (len(imgs), res, res) and masks.dtype == np.uint8
     for k, img in enumerate(imgs):
-        want, winfo = oracle.silhouette(img, res, margin, crop, None if min_size < 0 else min_size)
+        want, winfo = oracle_silhouette(oracle, img, res, margin, crop, None if min_size < 0 else min_size)
         np.testing.assert_array_equal(info[k], winfo, err_msg=f"info of image {k}")
         bad = np.argwhere(masks[k] != want)
         assert bad.size == 0, f"image {k}: {len(bad)} pixels differ, first at {bad[0]}"
@@ -50,7 +67,25 @@ def test_golden_masks_of_the_reference(gpu):
         assert set(np.unique(masks)) <= {0, 255}
 
 
-def test_view_panels_against_oracle(gpu, oracle, hu_panels):
+def test_production_panels_of_the_reference(gpu, hu_panels):
+    """OpenCV branch against the reference's own artefacts: for the 21 ids whose
+    preview collage is committed, the device's silhouette of raw view_01 equals
+    the mask panel and its gray crop equals the crop panel, pixel for pixel."""
+    global BACKEND
+    BACKEND = "opencv"
+    try:
+        raw = np.ascontiguousarray(hu_panels["raw_views"][:, 0])
+        masks, info = run(gpu, raw, 224, 0.05, True)
+        gray = fit(gpu, raw, info, 224, 255)
+    finally:
+        BACKEND = "pil"
+    for i, sid in enumerate(hu_panels["ids"]):
+        assert int((masks[i] != hu_panels["masks"][i]).sum()) == 0, f"mask of {sid}"
+        assert int((gray[i] != hu_panels["preproc"][i]).sum()) == 0, f"gray crop of {sid}"
+    assert np.all(info[:, 1] == 1)   # dark trees on white: the class above the level is the background
+
+
+def test_view_panels_against_oracle(gpu, oracle, hu_panels, backend):
     raw = hu_panels["raw_views"].reshape(-1, 224, 224)
     check(gpu, oracle, raw, 224, 0.05, True)
     check(gpu, oracle, raw[:12], 224, 0.05, False)
@@ -60,14 +95,14 @@ def test_view_panels_against_oracle(gpu, oracle, hu_panels):
 
 @pytest.mark.parametrize("h,w,res", [(224, 224, 224), (97, 131, 100), (131, 97, 75), (512, 512, 512), (300, 480, 224),
                                      (64, 64, 224), (33, 500, 96), (16, 16, 16)])
-def test_synthetic_scenes(gpu, oracle, h, w, res):
+def test_synthetic_scenes(gpu, oracle, h, w, res, backend):
     rng = np.random.default_rng(h * 1000 + w)
     imgs = np.stack([gray_scene(rng, h, w, dark_object=bool(k & 1), noise=4.0 + 6 * k, blobs=1 + k) for k in range(6)])
     check(gpu, oracle, imgs, res, 0.05, True)
     check(gpu, oracle, imgs, res, 0.0, False)
 
 
-def test_noise_images_many_components(gpu, oracle):
+def test_noise_images_many_components(gpu, oracle, backend):
     """Pure noise: thousands of runs (the run table leaves LDS), many components
     below min_size, the keep-largest rule when nothing reaches min_size."""
     rng = np.random.default_rng(77)
@@ -80,7 +115,7 @@ def test_noise_images_many_components(gpu, oracle):
     check(gpu, oracle, big, 512, 0.05, False)
 
 
-def test_degenerate_views(gpu, oracle):
+def test_degenerate_views(gpu, oracle, backend):
     flat = np.full((3, 224, 224), 255, dtype=np.uint8)
     flat[1] = 0
     flat[2, 100:103, 50:53] = 7             # 3x3 speck: survives the openings exactly
@@ -98,17 +133,31 @@ def test_degenerate_views(gpu, oracle):
     frame[1, 60:64, 70:74] = 20
     check(gpu, oracle, frame, 96, 0.05, False, min_size=1000)
     check(gpu, oracle, frame, 96, 0.1, True)
+    # nested shapes: a blob inside a ring inside a ring (only the outermost border is an external contour),
+    # shapes that touch diagonally, and equal areas
+    nest = np.full((3, 128, 128), 240, dtype=np.uint8)
+    nest[0, 10:118, 10:118] = 20
+    nest[0, 30:98, 30:98] = 240
+    nest[0, 50:78, 50:78] = 20
+    nest[0, 2:8, 120:126] = 20
+    nest[1, 20:60, 20:60] = 20
+    nest[1, 60:100, 60:100] = 20
+    nest[1, 100:120, 10:30] = 20
+    nest[2, 10:40, 10:40] = 20
+    nest[2, 80:110, 70:100] = 20
+    check(gpu, oracle, nest, 128, 0.05, True)
+    check(gpu, oracle, nest, 64, 0.0, True, min_size=5000)
 
 
-def test_padded_rows_and_empty_batch(gpu, oracle):
+def test_padded_rows_and_empty_batch(gpu, oracle, backend):
     eng = pkg("engine")
     rng = np.random.default_rng(9)
     imgs = np.stack([gray_scene(rng, 120, 150) for _ in range(3)])
     wide = torch.zeros((3, 120, 176), dtype=torch.uint8, device=gpu)
     wide[:, :, :150] = torch.from_numpy(imgs).to(gpu)
-    out = eng.silhouette_batch(wide[:, :, :150], 112, 0.05, True)["mask"].cpu().numpy()
+    out = eng.silhouette_batch(wide[:, :, :150], 112, 0.05, True, backend=backend)["mask"].cpu().numpy()
     for k in range(3):
-        np.testing.assert_array_equal(out[k], oracle.silhouette(imgs[k], 112, 0.05, True)[0])
+        np.testing.assert_array_equal(out[k], oracle_silhouette(oracle, imgs[k], 112, 0.05, True)[0])
     empty = eng.silhouette_batch(torch.zeros((0, 64, 64), dtype=torch.uint8, device=gpu), 32)
     assert tuple(empty["mask"].shape) == (0, 32, 32)
 
@@ -123,18 +172,18 @@ def test_rejects_unsupported_sizes(gpu):
         eng.silhouette_batch(torch.zeros((1, 64, 64), dtype=torch.float32, device=gpu), 64)
 
 
-def test_large_batch_is_deterministic_and_chunked(gpu, oracle):
+def test_large_batch_is_deterministic_and_chunked(gpu, oracle, backend):
     """More views than one internal chunk of blurred scratch holds at 512x512."""
     rng = np.random.default_rng(21)
     base = np.stack([gray_scene(rng, 512, 512, dark_object=bool(k & 1)) for k in range(8)])
     reps = 640                                            # 5120 views x 256 KiB > 1 GiB
     d = torch.from_numpy(base).to(gpu).repeat(reps, 1, 1)
     eng = pkg("engine")
-    out = eng.silhouette_batch(d, 224, 0.05, True)["mask"]
+    out = eng.silhouette_batch(d, 224, 0.05, True, backend=backend)["mask"]
     torch.cuda.synchronize()
     first = out[:8].cpu().numpy()
     for k in range(8):
-        np.testing.assert_array_equal(first[k], oracle.silhouette(base[k], 224, 0.05, True)[0])
+        np.testing.assert_array_equal(first[k], oracle_silhouette(oracle, base[k], 224, 0.05, True)[0])
     assert torch.equal(out.view(reps, 8, 224, 224), out[:8].unsqueeze(0).expand(reps, -1, -1, -1))
 
 
@@ -182,8 +231,12 @@ def test_preprocess_image_signature(gpu, oracle, hu_panels):
     hu = pkg("extract_2d_hu")
     img = hu_panels["raw_views"][3, 1]
     for crop in (False, True):
-        pre, mask = hu.preprocess_image(img, 224, 0.05, "white", crop)
+        pre, mask = hu.preprocess_image(img, 224, 0.05, "white", crop, backend="pil")
         wpre, wmask = oracle.preprocess_image(img, 224, 0.05, "white", crop)
+        np.testing.assert_array_equal(pre, wpre)
+        np.testing.assert_array_equal(mask, wmask)
+        pre, mask = hu.preprocess_image(img, 224, 0.05, "white", crop)     # default: the OpenCV branch
+        wpre, wmask = oracle.preprocess_image_cv(img, 224, 0.05, "white", crop)
         np.testing.assert_array_equal(pre, wpre)
         np.testing.assert_array_equal(mask, wmask)
     np.testing.assert_array_equal(hu.pad_and_resize(img[10:200, 30:180], 96, "black"),
