@@ -446,7 +446,7 @@ def main(argv=None):
                        "bytes_per_unit": wl["bytes_per_unit"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": {"pca": "pca_sets_reg_kernel", "hu": "hu_band_kernel", "hu+cpca": "hu_band_kernel",
+                         "kernel": {"pca": "pca_sets_full_kernel", "hu": "hu_band_kernel", "hu+cpca": "hu_band_kernel",
                                     "tail": "hu_band_kernel", "sil+hu": "sil_mask_kernel",
                                     "views+hu": "render_views_kernel"}[kind],
                          "kernel_ms": kavg, "units_per_launch": units},

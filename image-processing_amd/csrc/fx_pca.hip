@@ -572,6 +572,266 @@ __global__ __launch_bounds__(FX_WAVE *NW, FX_PCA_WAVES) void pca_sets_reg_kernel
     }
 }
 
+// ------------------------------------------------- full sets: the C4 kernel
+// Equal-sized, 16-byte aligned 3-D sets of exactly 64 * PPL points (the
+// pipeline's 1024-point clouds): no per-point predicates, 1 / n and
+// 1 / (n - 1) from the host.  Same float64 arithmetic as pca_sets_reg_kernel.
+// What differs is how the few points are handled that float32 cannot settle
+// (the candidates for the exact maximum, points within rounding of a bin
+// edge): instead of a float64 branch per point index (thirty-two inlined
+// copies, the widened coordinates kept alive for them) such points are
+// appended to a short LDS list and evaluated afterwards, a lane per point.
+// The float32 pre-value of the projection is three FMAs on the raw
+// coordinates (v.x - v.mean); its error bound grows with the distance of the
+// set from the origin (sets far away send more points to the float64 path,
+// results are the same).
+template <int PPL, int NW, bool NORMALIZE>
+__global__ __launch_bounds__(FX_WAVE *NW, FX_PCA_WAVES) void pca_sets_full_kernel(PcaArgs A, double inv_n, double inv_nm1)
+{
+    constexpr int HIST_COPIES = 8, HIST_PITCH = HIST_MAX + 1;
+    __shared__ uint32_t hist_all[NW][HIST_COPIES * HIST_PITCH];
+    __shared__ double red_all[NW][RED9_WORDS];
+    __shared__ double cov_all[NW][6], eig_all[NW][6];
+    const int lane = fx_lane(), wave = fx_wave();
+    constexpr int n = FX_WAVE * PPL;
+    constexpr int G = PPL / 4;  // 4-point groups (48 bytes) per lane
+    const int64_t slot = (int64_t)blockIdx.x * NW + wave;
+    uint32_t *hist = hist_all[wave];
+    uint32_t *my_hist = hist + (lane % HIST_COPIES) * HIST_PITCH;
+    const int nb = A.n_bins;
+    const int width = 9 + nb;
+
+    {
+        // a wave past the last set stays for the block barriers: it works on the last set and writes nothing
+        const bool live = slot < A.n_sets;
+        const int64_t set = live ? slot : A.n_sets - 1;
+        const float4 *g4 = reinterpret_cast<const float4 *>(A.pts + set * (int64_t)(3 * n));
+        float x[PPL], y[PPL], z[PPL];
+#pragma unroll
+        for (int k = 0; k < G; k++) {
+            const int grp = lane + FX_WAVE * k;  // points 4 * grp .. 4 * grp + 3
+            const float4 a = g4[3 * grp], b = g4[3 * grp + 1], c = g4[3 * grp + 2];
+            x[4 * k] = a.x, y[4 * k] = a.y, z[4 * k] = a.z;
+            x[4 * k + 1] = a.w, y[4 * k + 1] = b.x, z[4 * k + 1] = b.y;
+            x[4 * k + 2] = b.z, y[4 * k + 2] = b.w, z[4 * k + 2] = c.x;
+            x[4 * k + 3] = c.y, y[4 * k + 3] = c.z, z[4 * k + 3] = c.w;
+        }
+#pragma unroll
+        for (int k = 0; k < HIST_COPIES; k++)
+            hist[k * HIST_PITCH + lane] = 0;
+
+        // pivot = the set's first point (lane 0, group 0)
+        const float kx32 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x[0])));
+        const float ky32 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(y[0])));
+        const float kz32 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(z[0])));
+        const double kx = kx32, ky = ky32, kz = kz32;
+        double v9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < PPL; i++) {
+            const double dx = (double)x[i] - kx, dy = (double)y[i] - ky, dz = (double)z[i] - kz;
+            v9[0] += dx;
+            v9[1] += dy;
+            v9[2] += dz;
+            v9[3] = fma(dx, dx, v9[3]);
+            v9[4] = fma(dx, dy, v9[4]);
+            v9[5] = fma(dx, dz, v9[5]);
+            v9[6] = fma(dy, dy, v9[6]);
+            v9[7] = fma(dy, dz, v9[7]);
+            v9[8] = fma(dz, dz, v9[8]);
+        }
+        wave_sum9(v9, red_all[wave]);
+        const double ox = v9[0] * inv_n, oy = v9[1] * inv_n, oz = v9[2] * inv_n;  // mean - pivot
+        const double mx = kx + ox, my = ky + oy, mz = kz + oz;
+        double S[6];
+        S[0] = fma(-v9[0], ox, v9[3]);
+        S[1] = fma(-v9[0], oy, v9[4]);
+        S[2] = fma(-v9[0], oz, v9[5]);
+        S[3] = fma(-v9[1], oy, v9[6]);
+        S[4] = fma(-v9[1], oz, v9[7]);
+        S[5] = fma(-v9[2], oz, v9[8]);
+        // every centred point lies within sqrt(sum of squared distances) of the mean
+        float reach32 = sqrtf((float)(S[0] + S[3] + S[5])) * 1.000001f;
+
+        // NORMALIZE is a template argument: as a run-time branch it makes the compiler keep all widened
+        // coordinates of the first pass alive for this one (48 more registers, one wave less per SIMD)
+        double rmax = 0.0;
+        if (NORMALIZE) {
+            double r2 = 0.0;
+#pragma unroll
+            for (int i = 0; i < PPL; i++) {
+                const double dx = (double)x[i] - mx, dy = (double)y[i] - my, dz = (double)z[i] - mz;
+                r2 = fmax(r2, dx * dx + dy * dy + dz * dz);
+            }
+            rmax = sqrt(fx_wave_max_f64_dpp(r2));
+        }
+        const bool scale = NORMALIZE && rmax > 0.0;
+        if (scale) {
+            const double w = 1.0 / (rmax * rmax);
+#pragma unroll
+            for (int k = 0; k < 6; k++)
+                S[k] *= w;
+        }
+
+        // eigen-solve: one wave of the block, a lane per set (see pca_sets_reg_kernel)
+        double lam[3], v1[3];
+        {
+            if (lane < 6) {
+                double c = S[0];
+                c = lane == 1 ? S[1] : c;
+                c = lane == 2 ? S[2] : c;
+                c = lane == 3 ? S[3] : c;
+                c = lane == 4 ? S[4] : c;
+                c = lane == 5 ? S[5] : c;
+                cov_all[wave][lane] = c * inv_nm1;  // np.cov multiplies by 1/(n-1)
+            }
+            __syncthreads();
+            if (wave == (int)(blockIdx.x % NW) && lane < NW) {
+                const double *c = cov_all[lane];
+                double l3[3], w3[3];
+                fx_eig3<true>(c[0], c[1], c[2], c[3], c[4], c[5], l3, w3);
+                double *e = eig_all[lane];
+                e[0] = l3[0], e[1] = l3[1], e[2] = l3[2];
+                e[3] = w3[0], e[4] = w3[1], e[5] = w3[2];
+            }
+            __syncthreads();
+            const double *e = eig_all[wave];
+            lam[0] = e[0], lam[1] = e[1], lam[2] = e[2];
+            v1[0] = e[3], v1[1] = e[4], v1[2] = e[5];
+        }
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+            lam[q] = lam[q] < 0.0 ? 0.0 : lam[q];
+        const double trace = lam[0] + lam[1] + lam[2];
+        double head_mine;
+        {
+            const double safe = trace > 1e-12 ? trace : 1e-12;
+            const int e = lane < 9 ? lane : 0;
+            const double num = (e == 0 || e == 3 || e == 6) ? lam[0] : (e == 1 || e == 4 || e == 7) ? lam[1] : (e == 2 || e == 5) ? lam[2] : trace;
+            const double den = e < 3 || e == 8 ? 1.0 : e < 6 ? safe : e == 6 ? lam[1] + 1e-12 : lam[2] + 1e-12;
+            head_mine = num / den;
+        }
+
+        // float64 value of a point (the formula of record)
+        auto proj = [&](float px, float py, float pz) -> double {
+            double dx = (double)px - mx, dy = (double)py - my, dz = (double)pz - mz;
+            if (scale) {
+                dx /= rmax;
+                dy /= rmax;
+                dz /= rmax;
+            }
+            return fabs(fma(dz, v1[2], fma(dy, v1[1], dx * v1[0])));
+        };
+        // float32 value: v.x - v.mean in three FMAs.  Each of its five roundings is relative to a partial sum
+        // of at most |v.mean| + |v| |x| <= w (|mean|_1 + |mean|_2 + reach): eps32 bounds the total generously.
+        // It settles every point that is not within eps32 of a decision; those few are decided in float64,
+        // one point index at a time for the whole wave, so that the float64 code exists once.
+        const float w32 = scale ? (float)(1.0 / rmax) : 1.0f;
+        const float vx32 = (float)v1[0] * w32, vy32 = (float)v1[1] * w32, vz32 = (float)v1[2] * w32;
+        const float c32 = (float)(fma(v1[2], mz, fma(v1[1], my, v1[0] * mx))) * w32;
+        const float m1 = fabsf((float)mx) + fabsf((float)my) + fabsf((float)mz);
+        const float eps32 = 1e-6f * w32 * (2.0f * m1 + reach32) + 1e-37f;
+        float top32 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < PPL; i++)
+            top32 = fmaxf(top32, fabsf(fmaf(z[i], vz32, fmaf(y[i], vy32, fmaf(x[i], vx32, -c32)))));
+        top32 = fx_wave_max_f32_dpp(top32);
+        const float cand32 = top32 - 2.0f * eps32;  // the exact maximum is among the points at or above this
+        // Points that float32 cannot settle are appended to a short list in LDS (a wave-uniform branch per point
+        // index, taken for about one index in sixteen) and evaluated in float64 afterwards, a lane per listed
+        // point: the float64 code exists once and runs without divergence.
+        float *slow_list = reinterpret_cast<float *>(red_all[wave]);  // the reduction slab is free again
+        constexpr int SLOW_CAP = (RED9_WORDS * 2) / 3 - FX_WAVE;  // points the slab holds, one wave's worth in reserve
+        int n_slow = 0;
+        auto append = [&](unsigned long long mask, float px, float py, float pz) {
+            const int pos = n_slow + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            if ((mask >> lane) & 1ull) {
+                slow_list[3 * pos] = px;
+                slow_list[3 * pos + 1] = py;
+                slow_list[3 * pos + 2] = pz;
+            }
+            n_slow += __builtin_popcountll(mask);
+        };
+        double top = 0.0;
+        auto drain_top = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int e = lane; e < n_slow; e += FX_WAVE)
+                top = fmax(top, proj(slow_list[3 * e], slow_list[3 * e + 1], slow_list[3 * e + 2]));
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            n_slow = 0;
+        };
+#pragma unroll
+        for (int i = 0; i < PPL; i++) {
+            const float p = fabsf(fmaf(z[i], vz32, fmaf(y[i], vy32, fmaf(x[i], vx32, -c32))));
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(p >= cand32);
+            if (mask) {
+                if (n_slow > SLOW_CAP)   // degenerate sets (all points at the same |projection|): work the list off first
+                    drain_top();
+                append(mask, x[i], y[i], z[i]);
+            }
+        }
+        drain_top();
+        top = fx_wave_max_f64_dpp(top);
+
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (top > 0.0) {
+            const double step = top / (double)nb;
+            const double inv_step = (double)nb / top;
+            // q = |projection| / step in float32 with the scale folded into the direction; a point whose q lies
+            // within `margin` of an integer (a bin edge; the top edge included, since q cannot exceed n_bins by
+            // more than its rounding) is left to float64 and counted in the pad word of the histogram for now
+            const float inv32 = (float)inv_step;
+            const float qx = vx32 * inv32, qy = vy32 * inv32, qz = vz32 * inv32, qc = c32 * inv32;
+            const float margin = 2.0f * (eps32 + 3e-7f * top32) * inv32 + 1e-5f * (float)nb;
+            auto drain_bins = [&]() {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (int e = lane; e < n_slow; e += FX_WAVE)
+                    atomicAdd(&my_hist[fx_hist_bin(proj(slow_list[3 * e], slow_list[3 * e + 1], slow_list[3 * e + 2]), step,
+                                                   inv_step, nb)], 1u);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                n_slow = 0;
+            };
+#pragma unroll
+            for (int i = 0; i < PPL; i++) {
+                const float q = fabsf(fmaf(z[i], qz, fmaf(y[i], qy, fmaf(x[i], qx, -qc))));
+                const bool slow = fabsf(q - rintf(q)) < margin;
+                atomicAdd(&my_hist[slow ? HIST_MAX : (int)q], 1u);
+                const unsigned long long mask = __builtin_amdgcn_ballot_w64(slow);
+                if (mask) {
+                    if (n_slow > SLOW_CAP)
+                        drain_bins();
+                    append(mask, x[i], y[i], z[i]);
+                }
+            }
+            drain_bins();
+            if (live && lane < nb) {
+                uint32_t h = 0;
+#pragma unroll
+                for (int k = 0; k < HIST_COPIES; k++)
+                    h += hist[k * HIST_PITCH + lane];
+                A.out[set * width + 9 + lane] = (float)h / (float)n;
+            }
+        } else if (live && lane < nb) {
+            A.out[set * width + 9 + lane] = lane == 0 ? 1.0f : 0.0f;
+        }
+        if (live && lane < 9)
+            A.out[set * width + lane] = (float)head_mine;
+        if (live && A.eig && lane < 6) {
+            double e = lam[0];
+            e = lane == 1 ? lam[1] : e;
+            e = lane == 2 ? lam[2] : e;
+            e = lane == 3 ? v1[0] : e;
+            e = lane == 4 ? v1[1] : e;
+            e = lane == 5 ? v1[2] : e;
+            A.eig[set * 6 + lane] = e;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- large sets
 // Clouds that do not fit a wave's LDS slab are cut into chunks of CLOUD_CHUNK
 // points; every pass over the data is one launch with one block per chunk, so
@@ -882,9 +1142,30 @@ int launch_wave_kernel(PcaArgs A, int64_t max_points, hipStream_t s)
 
 constexpr int64_t REG_SET_MAX_POINTS = 1024;  // 3-D sets up to this size are kept in registers
 
+template <int PPL>
+int launch_full_sets(const PcaArgs &A, hipStream_t s)
+{
+    constexpr int NW = FX_PCA_NW;
+    auto k = A.normalize ? pca_sets_full_kernel<PPL, NW, true> : pca_sets_full_kernel<PPL, NW, false>;
+    const int64_t blocks = (A.n_sets + NW - 1) / NW;
+    FX_REQUIRE(blocks <= 0x7fffffffLL, "fx_pca_batch_f32: too many sets for one launch");
+    const int64_t n = (int64_t)FX_WAVE * PPL;
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(FX_WAVE * NW), 0, s, A, 1.0 / (double)n, 1.0 / (double)(n - 1));
+    FX_HIP_CHECK(hipGetLastError());
+    return FX_OK;
+}
+
 int launch_reg_sets(const PcaArgs &A, int64_t max_points, bool ragged, hipStream_t s)
 {
     constexpr int NW = FX_PCA_NW;  // sets (waves) per block
+    if (!ragged && !A.offsets && !A.set_ids) {
+        if (max_points == 1024)
+            return launch_full_sets<16>(A, s);
+        if (max_points == 512)
+            return launch_full_sets<8>(A, s);
+        if (max_points == 256)
+            return launch_full_sets<4>(A, s);
+    }
     const int64_t blocks = (A.n_sets + NW - 1) / NW;
     FX_REQUIRE(blocks <= 0x7fffffffLL, "fx_pca_batch_f32: too many sets for one launch");
     const dim3 grid((unsigned)blocks), block(FX_WAVE * NW);

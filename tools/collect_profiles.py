@@ -14,15 +14,15 @@ from collections import defaultdict
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-DOMINANT = {"c3": "hu_band_kernel", "c2": "hu_band_kernel", "c4": "pca_sets_reg_kernel", "c5": "hu_band_kernel",
+DOMINANT = {"c3": "hu_band_kernel", "c2": "hu_band_kernel", "c4": "pca_sets_full_kernel", "c5": "hu_band_kernel",
             "f1": "sil_mask_kernel"}
 UNITS = {"c3": (125000, 262144), "c2": (100000, 65536), "c4": (1000000, 12288), "c5": (64, 67108864), "f1": (20000, 50176)}
 # FETCH_SIZE on gfx950 tallies the 128-byte requests of a 16 B/lane coalesced stream at 64 bytes, i.e. half the
 # bytes; other request mixes are uncalibrated.  The factor is applied only to kernels whose loads are all
-# 16 B/lane (hu_band_kernel: one global_load_dwordx4 per chunk; pca_sets_reg_kernel, aligned variant: three
+# 16 B/lane (hu_band_kernel: one global_load_dwordx4 per chunk; pca_sets_full_kernel: three
 # float4 per lane), each of which reads its input exactly once, so the corrected figure can be checked against
 # the algorithmic byte count (ratio recorded below).  Kernels with another request mix get no traffic figure.
-FETCH_FACTOR = {"hu_band_kernel": 2.0, "pca_sets_reg_kernel": 2.0}
+FETCH_FACTOR = {"hu_band_kernel": 2.0, "pca_sets_full_kernel": 2.0}
 
 
 def short(name):

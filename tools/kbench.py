@@ -154,6 +154,10 @@ if __name__ == "__main__":
     elif what == "sil1":
         ms, gbps = time_sil(20000, 224, 224, 224, reps=3)
         print(f"sil B=20000 224x224->224: {ms:.3f} ms  {gbps:.0f} GB/s", flush=True)
+    elif what == "pca1m":
+        for (B, N) in [(1000000, 1024), (1000000, 256), (500000, 512)]:
+            ms, gbps = time_pca(B, N, reps=12)
+            print(f"pca B={B} N={N}: {ms:.3f} ms  {gbps:.0f} GB/s  ({os.environ.get('FX_LIB', 'libfx.so')})", flush=True)
     elif what == "sil":
         for (B,H,W,res) in [(20000,224,224,224),(100000,224,224,224),(20000,512,512,224)]:
             ms, gbps = time_sil(B,H,W,res)
