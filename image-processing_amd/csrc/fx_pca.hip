@@ -29,6 +29,7 @@ struct PcaArgs {
     float *out;
     double *eig;
     int slab_floats;  // LDS floats per wave (wave kernel)
+    const int32_t *n_sets_dev;  // when set: the number of entries of set_ids, known on the device only
 };
 
 constexpr int HIST_MAX = 64;
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(FX_WAVE *WPB) void pca_sets_wave_kernel(PcaArgs A)
     extern __shared__ __align__(16) float lds[];
     const int lane = fx_lane(), wave = fx_wave();
     const int64_t slot = (int64_t)blockIdx.x * WPB + wave;
-    if (slot >= A.n_sets)
+    if (slot >= (A.n_sets_dev ? (int64_t)*A.n_sets_dev : A.n_sets))
         return;  // whole wave leaves; no block-level barrier is used below
     const SetView sv = resolve_set(A, slot);
     const int64_t set = sv.set;
@@ -338,8 +339,11 @@ __global__ __launch_bounds__(FX_WAVE *NW, FX_PCA_WAVES) void pca_sets_reg_kernel
     __shared__ double cov_all[NW][6], eig_all[NW][6];
     const int lane = fx_lane(), wave = fx_wave();
     const int64_t slot = (int64_t)blockIdx.x * NW + wave;
+    const int64_t n_sets = A.n_sets_dev ? (int64_t)*A.n_sets_dev : A.n_sets;
+    if ((int64_t)blockIdx.x * NW >= n_sets)
+        return;  // a surplus block of a launch sized by an upper bound (the whole block leaves, before any barrier)
     // a wave past the last set stays for the block barriers: it works on the first set and writes nothing
-    const bool in_range = slot < A.n_sets;
+    const bool in_range = slot < n_sets;
     const SetView sv = resolve_set(A, in_range ? slot : 0);
     const int64_t set = sv.set;
     const int n = (int)sv.n;
@@ -854,6 +858,10 @@ struct CloudWork {
     double *part;                // [n_chunks][PART]
     uint32_t *hpart;             // [n_chunks][HIST_MAX]
     double *state;               // [n_clouds][STATE]
+    // device-built work lists (ragged batches classified on the device): the counts live in device memory
+    // and the launches use a fixed grid whose blocks loop; NULL = the grid is the list
+    const int32_t *n_chunks_dev;
+    const int32_t *n_clouds_dev;
 };
 
 struct ChunkView {
@@ -923,10 +931,9 @@ __device__ __forceinline__ CloudPoint cloud_point(const float *g, int64_t i, int
     return p;
 }
 
-__global__ __launch_bounds__(CLOUD_THREADS) void cloud_sum_kernel(PcaArgs A, CloudWork Wk)
+__device__ __forceinline__ void cloud_sum_body(const PcaArgs &A, const CloudWork &Wk, const int chunk, double *red)
 {
-    __shared__ double red[CLOUD_WAVES];
-    const ChunkView v = chunk_view(A, Wk, blockIdx.x);
+    const ChunkView v = chunk_view(A, Wk, chunk);
     double sx = 0.0, sy = 0.0, sz = 0.0;
     for (int64_t i = v.i0 + threadIdx.x; i < v.i1; i += CLOUD_THREADS) {
         const CloudPoint p = cloud_point(v.g, i, A.dims);
@@ -938,7 +945,7 @@ __global__ __launch_bounds__(CLOUD_THREADS) void cloud_sum_kernel(PcaArgs A, Clo
     sy = cloud_block_reduce<false>(sy, red);
     sz = cloud_block_reduce<false>(sz, red);
     if (threadIdx.x == 0) {
-        double *out = Wk.part + (int64_t)blockIdx.x * PART;
+        double *out = Wk.part + (int64_t)chunk * PART;
         out[0] = sx;
         out[1] = sy;
         out[2] = sz;
@@ -947,15 +954,14 @@ __global__ __launch_bounds__(CLOUD_THREADS) void cloud_sum_kernel(PcaArgs A, Clo
 
 // STAGE 0: max r^2 of the centred points (normalize only); STAGE 1: centred second moments.
 template <int STAGE>
-__global__ __launch_bounds__(CLOUD_THREADS) void cloud_moment_kernel(PcaArgs A, CloudWork Wk)
+__device__ __forceinline__ void cloud_moment_body(const PcaArgs &A, const CloudWork &Wk, const int chunk, double *red)
 {
-    __shared__ double red[CLOUD_WAVES];
-    const ChunkView v = chunk_view(A, Wk, blockIdx.x);
+    const ChunkView v = chunk_view(A, Wk, chunk);
     const double dn = (double)v.n;
     const double mx = cloud_combine<false>(Wk.part, v.first, v.nch, 0, red) / dn;
     const double my = cloud_combine<false>(Wk.part, v.first, v.nch, 1, red) / dn;
     const double mz = cloud_combine<false>(Wk.part, v.first, v.nch, 2, red) / dn;
-    double *out = Wk.part + (int64_t)blockIdx.x * PART;
+    double *out = Wk.part + (int64_t)chunk * PART;
     if (STAGE == 0) {
         double r2 = 0.0;
         for (int64_t i = v.i0 + threadIdx.x; i < v.i1; i += CLOUD_THREADS) {
@@ -994,7 +1000,7 @@ __global__ __launch_bounds__(CLOUD_THREADS) void cloud_moment_kernel(PcaArgs A, 
         if (threadIdx.x == 0)
             out[4 + k] = tot;
     }
-    if (threadIdx.x == 0 && blockIdx.x == (unsigned)v.first) {
+    if (threadIdx.x == 0 && chunk == v.first) {
         double *st = Wk.state + (int64_t)v.cloud * STATE;
         st[0] = mx;
         st[1] = my;
@@ -1017,10 +1023,9 @@ __device__ __forceinline__ double cloud_projection(const CloudPoint &p, const do
 // Covariance -> eigen-solve (every block of the cloud repeats it: a few hundred
 // instructions) -> largest |projection| of the chunk.  The cloud's first block
 // also writes the nine scalars and the axis.
-__global__ __launch_bounds__(CLOUD_THREADS) void cloud_proj_kernel(PcaArgs A, CloudWork Wk)
+__device__ __forceinline__ void cloud_proj_body(const PcaArgs &A, const CloudWork &Wk, const int chunk, double *red)
 {
-    __shared__ double red[CLOUD_WAVES];
-    const ChunkView v = chunk_view(A, Wk, blockIdx.x);
+    const ChunkView v = chunk_view(A, Wk, chunk);
     double S[6];
 #pragma unroll
     for (int k = 0; k < 6; k++)
@@ -1041,8 +1046,8 @@ __global__ __launch_bounds__(CLOUD_THREADS) void cloud_proj_kernel(PcaArgs A, Cl
         top = fmax(top, cloud_projection(cloud_point(v.g, i, A.dims), st));
     top = cloud_block_reduce<true>(top, red);
     if (threadIdx.x == 0) {
-        Wk.part[(int64_t)blockIdx.x * PART + 10] = top;
-        if (blockIdx.x == (unsigned)v.first) {
+        Wk.part[(int64_t)chunk * PART + 10] = top;
+        if (chunk == v.first) {
             const int width = 9 + A.n_bins;
             for (int k = 0; k < 9; k++)
                 A.out[v.set * width + k] = (float)head[k];
@@ -1056,7 +1061,7 @@ __global__ __launch_bounds__(CLOUD_THREADS) void cloud_proj_kernel(PcaArgs A, Cl
     }
     // the axis goes to the cloud record for the histogram pass; every block of
     // the cloud computed the same values, the first one stores them
-    if (threadIdx.x == 0 && blockIdx.x == (unsigned)v.first) {
+    if (threadIdx.x == 0 && chunk == v.first) {
         double *wst = Wk.state + (int64_t)v.cloud * STATE;
         wst[4] = v1[0];
         wst[5] = v1[1];
@@ -1064,11 +1069,9 @@ __global__ __launch_bounds__(CLOUD_THREADS) void cloud_proj_kernel(PcaArgs A, Cl
     }
 }
 
-__global__ __launch_bounds__(CLOUD_THREADS) void cloud_hist_kernel(PcaArgs A, CloudWork Wk)
+__device__ __forceinline__ void cloud_hist_body(const PcaArgs &A, const CloudWork &Wk, const int chunk, double *red, uint32_t *hist)
 {
-    __shared__ double red[CLOUD_WAVES];
-    __shared__ uint32_t hist[HIST_MAX];
-    const ChunkView v = chunk_view(A, Wk, blockIdx.x);
+    const ChunkView v = chunk_view(A, Wk, chunk);
     if (threadIdx.x < HIST_MAX)
         hist[threadIdx.x] = 0;
     const double top = cloud_combine<true>(Wk.part, v.first, v.nch, 10, red);  // its barriers cover the zeroing
@@ -1086,16 +1089,15 @@ __global__ __launch_bounds__(CLOUD_THREADS) void cloud_hist_kernel(PcaArgs A, Cl
     }
     __syncthreads();
     if (threadIdx.x < HIST_MAX)
-        Wk.hpart[(int64_t)blockIdx.x * HIST_MAX + threadIdx.x] = hist[threadIdx.x];
+        Wk.hpart[(int64_t)chunk * HIST_MAX + threadIdx.x] = hist[threadIdx.x];
 }
 
 // One block per cloud: add the chunk histograms (wave w takes chunks w, w + 4,
 // ..., lane = bin), normalise, write.  Integer sums, so the order is free.
-__global__ __launch_bounds__(FX_BLOCK) void cloud_finish_kernel(PcaArgs A, CloudWork Wk)
+__device__ __forceinline__ void cloud_finish_body(const PcaArgs &A, const CloudWork &Wk, const int cloud, double *tops,
+                                                  u64 (*cnts)[HIST_MAX])
 {
-    __shared__ double tops[FX_WAVES_PER_BLOCK];
-    __shared__ u64 cnts[FX_WAVES_PER_BLOCK][HIST_MAX];
-    const int cloud = blockIdx.x, lane = fx_lane(), wave = fx_wave();
+    const int lane = fx_lane(), wave = fx_wave();
     const int first = Wk.cloud_first[cloud], nch = Wk.cloud_first[cloud + 1] - first;
     const int64_t set = Wk.cloud_ids[cloud];
     const int64_t n = A.offsets ? A.offsets[set + 1] - A.offsets[set] : A.N;
@@ -1121,6 +1123,60 @@ __global__ __launch_bounds__(FX_BLOCK) void cloud_finish_kernel(PcaArgs A, Cloud
     }
     cnt = cnts[0][lane] + cnts[1][lane] + cnts[2][lane] + cnts[3][lane];
     out[lane] = (float)((double)cnt / (double)n);
+}
+
+// The launches of the chain: a block per chunk (or per cloud), or, when the lists were built on the device and
+// their lengths are not known to the host, a fixed grid whose blocks walk the list.
+__device__ __forceinline__ int cloud_list_length(const int32_t *dev_count)
+{
+    return dev_count ? *dev_count : (int)gridDim.x;
+}
+
+__global__ __launch_bounds__(CLOUD_THREADS) void cloud_sum_kernel(PcaArgs A, CloudWork Wk)
+{
+    __shared__ double red[CLOUD_WAVES];
+    const int n = cloud_list_length(Wk.n_chunks_dev);
+    for (int chunk = blockIdx.x; chunk < n; chunk += gridDim.x)
+        cloud_sum_body(A, Wk, chunk, red);
+}
+
+template <int STAGE>
+__global__ __launch_bounds__(CLOUD_THREADS) void cloud_moment_kernel(PcaArgs A, CloudWork Wk)
+{
+    __shared__ double red[CLOUD_WAVES];
+    const int n = cloud_list_length(Wk.n_chunks_dev);
+    for (int chunk = blockIdx.x; chunk < n; chunk += gridDim.x)
+        cloud_moment_body<STAGE>(A, Wk, chunk, red);
+}
+
+__global__ __launch_bounds__(CLOUD_THREADS) void cloud_proj_kernel(PcaArgs A, CloudWork Wk)
+{
+    __shared__ double red[CLOUD_WAVES];
+    const int n = cloud_list_length(Wk.n_chunks_dev);
+    for (int chunk = blockIdx.x; chunk < n; chunk += gridDim.x)
+        cloud_proj_body(A, Wk, chunk, red);
+}
+
+__global__ __launch_bounds__(CLOUD_THREADS) void cloud_hist_kernel(PcaArgs A, CloudWork Wk)
+{
+    __shared__ double red[CLOUD_WAVES];
+    __shared__ uint32_t hist[HIST_MAX];
+    const int n = cloud_list_length(Wk.n_chunks_dev);
+    for (int chunk = blockIdx.x; chunk < n; chunk += gridDim.x) {
+        cloud_hist_body(A, Wk, chunk, red, hist);
+        __syncthreads();  // the histogram has been written out before the next chunk clears it
+    }
+}
+
+__global__ __launch_bounds__(FX_BLOCK) void cloud_finish_kernel(PcaArgs A, CloudWork Wk)
+{
+    __shared__ double tops[FX_WAVES_PER_BLOCK];
+    __shared__ u64 cnts[FX_WAVES_PER_BLOCK][HIST_MAX];
+    const int n = cloud_list_length(Wk.n_clouds_dev);
+    for (int cloud = blockIdx.x; cloud < n; cloud += gridDim.x) {
+        cloud_finish_body(A, Wk, cloud, tops, cnts);
+        __syncthreads();
+    }
 }
 
 constexpr int64_t WAVE_SET_MAX_POINTS = 2048;  // sets up to this size take the LDS path
@@ -1196,6 +1252,106 @@ int launch_small_sets(const PcaArgs &A, int64_t max_points, hipStream_t s)
     return launch_wave_kernel<2>(A, max_points, s);
 }
 
+// ------------------------------------------------ ragged batches, lists on the device
+// A CSR batch is sorted into three work lists without the host ever seeing the
+// offsets: sets for the register kernel, sets for the LDS kernel, large clouds
+// (with their chunk lists).  The list lengths stay in device memory; the
+// launches that consume them are sized by upper bounds and their surplus blocks
+// leave at once (set kernels) or their blocks walk the list (cloud chain).
+struct RaggedLists {
+    int32_t *counts;       // [0] register sets, [1] LDS sets, [2] large clouds, [3] chunks
+    int32_t *reg_ids;      // [B]
+    int32_t *lds_ids;      // [B]
+    int32_t *cloud_ids;    // [max_clouds]
+    int32_t *cloud_first;  // [max_clouds + 1]
+    int32_t *chunk_cloud;  // [max_chunks]
+    int64_t max_clouds, max_chunks;
+};
+
+__global__ __launch_bounds__(FX_BLOCK) void pca_classify_kernel(PcaArgs A, RaggedLists L, int64_t B, int64_t reg_max)
+{
+    const int64_t b = (int64_t)blockIdx.x * FX_BLOCK + threadIdx.x;
+    int cls = -1;
+    if (b < B) {
+        // a set of fewer than three points (or with decreasing offsets) gets its NaN row from the set kernels
+        const int64_t n = A.offsets[b + 1] - A.offsets[b];
+        cls = n <= reg_max ? 0 : n <= WAVE_SET_MAX_POINTS ? 1 : 2;
+    }
+    const int lane = fx_lane();
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(cls == c);
+        if (!mask)
+            continue;
+        int base = 0;
+        if (lane == __builtin_ctzll(mask))
+            base = atomicAdd(&L.counts[c], (int)__builtin_popcountll(mask));   // one atomic per wave and list
+        base = __builtin_amdgcn_readlane(base, __builtin_ctzll(mask));
+        if (cls == c) {
+            const int pos = base + (int)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+            int32_t *list = c == 0 ? L.reg_ids : c == 1 ? L.lds_ids : L.cloud_ids;
+            if (c < 2 || pos < L.max_clouds)
+                list[pos] = (int32_t)b;
+        }
+    }
+}
+
+// One block: exclusive prefix of the clouds' chunk counts -> cloud_first, total -> counts[3].
+__global__ __launch_bounds__(1024) void pca_cloud_scan_kernel(PcaArgs A, RaggedLists L)
+{
+    __shared__ int wave_tot[16];
+    __shared__ int carry_s;
+    const int t = threadIdx.x, lane = fx_lane(), wave = fx_wave();
+    int n_clouds = L.counts[2];
+    n_clouds = n_clouds < L.max_clouds ? n_clouds : (int)L.max_clouds;
+    if (t == 0)
+        carry_s = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n_clouds; i0 += 1024) {
+        const int i = i0 + t;
+        int nch = 0;
+        if (i < n_clouds) {
+            const int64_t set = L.cloud_ids[i];
+            const int64_t n = A.offsets[set + 1] - A.offsets[set];
+            nch = (int)((n + CLOUD_CHUNK - 1) / CLOUD_CHUNK);
+        }
+        int inc = nch;
+#pragma unroll
+        for (int o = 1; o < FX_WAVE; o <<= 1) {
+            const int u = __shfl_up(inc, o, FX_WAVE);
+            if (lane >= o)
+                inc += u;
+        }
+        if (lane == FX_WAVE - 1)
+            wave_tot[wave] = inc;
+        __syncthreads();
+        int before = carry_s;
+        for (int w = 0; w < wave; w++)
+            before += wave_tot[w];
+        if (i < n_clouds)
+            L.cloud_first[i] = before + inc - nch;
+        __syncthreads();
+        if (t == 1023)
+            carry_s = before + inc;
+        __syncthreads();
+    }
+    if (t == 0) {
+        L.cloud_first[n_clouds] = carry_s;
+        L.counts[3] = carry_s < L.max_chunks ? carry_s : (int)L.max_chunks;
+        L.counts[2] = n_clouds;
+    }
+}
+
+__global__ __launch_bounds__(FX_BLOCK) void pca_chunk_fill_kernel(RaggedLists L)
+{
+    const int n_clouds = L.counts[2];
+    for (int i = blockIdx.x * FX_BLOCK + threadIdx.x; i < n_clouds; i += gridDim.x * FX_BLOCK) {
+        const int a = L.cloud_first[i], b = L.cloud_first[i + 1];
+        for (int c = a; c < b && c < L.max_chunks; c++)
+            L.chunk_cloud[c] = i;
+    }
+}
+
 // Builds the chunk lists for the given large clouds (set index + point count,
 // host arrays) and runs the passes.
 int launch_large_clouds(const PcaArgs &A, const int32_t *h_sets, const int64_t *h_sizes, int64_t n_clouds,
@@ -1247,6 +1403,8 @@ int launch_large_clouds(const PcaArgs &A, const int32_t *h_sets, const int64_t *
     Wk.part = (double *)(base + list_bytes);
     Wk.hpart = (uint32_t *)(base + list_bytes + part_bytes);
     Wk.state = (double *)(base + list_bytes + part_bytes + hist_bytes);
+    Wk.n_chunks_dev = nullptr;
+    Wk.n_clouds_dev = nullptr;
 
     const dim3 grid((unsigned)n_chunks), block(CLOUD_THREADS);
     hipLaunchKernelGGL(cloud_sum_kernel, grid, block, 0, s, A, Wk);
@@ -1256,6 +1414,88 @@ int launch_large_clouds(const PcaArgs &A, const int32_t *h_sets, const int64_t *
     hipLaunchKernelGGL(cloud_proj_kernel, grid, block, 0, s, A, Wk);
     hipLaunchKernelGGL(cloud_hist_kernel, grid, block, 0, s, A, Wk);
     hipLaunchKernelGGL(cloud_finish_kernel, dim3((unsigned)n_clouds), dim3(FX_BLOCK), 0, s, A, Wk);
+    FX_HIP_CHECK(hipGetLastError());
+    return FX_OK;
+}
+
+// Ragged batch without a host round trip: `total` is the caller's count of points behind d_pts (an upper bound
+// of offsets[B]), from which the sizes of the lists and of the per-chunk records are bounded.
+int launch_ragged_on_device(const PcaArgs &A, int64_t B, int64_t total, FxCallGuard &guard)
+{
+    hipStream_t s = guard.stream;
+    auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    // a large cloud has more than WAVE_SET_MAX_POINTS points, so there are at most total / (that + 1) of them,
+    // and sum ceil(n / chunk) <= total / chunk + number of clouds
+    int64_t max_clouds = total / (WAVE_SET_MAX_POINTS + 1);
+    max_clouds = max_clouds > B ? B : max_clouds;
+    const int64_t max_chunks = max_clouds ? total / CLOUD_CHUNK + max_clouds : 0;
+    FX_REQUIRE(max_chunks <= 0x7fffffffLL, "fx_pca_batch_f32: too many chunks for one launch");
+    const size_t counts_bytes = 256;
+    const size_t ids_bytes = align((size_t)B * sizeof(int32_t));
+    const size_t cid_bytes = align((size_t)(max_clouds + 1) * sizeof(int32_t));
+    const size_t cc_bytes = align((size_t)max_chunks * sizeof(int32_t));
+    const size_t part_bytes = align((size_t)max_chunks * PART * sizeof(double));
+    const size_t hist_bytes = align((size_t)max_chunks * HIST_MAX * sizeof(uint32_t));
+    const size_t state_bytes = align((size_t)max_clouds * STATE * sizeof(double));
+    unsigned char *base = (unsigned char *)guard.scratch(
+        counts_bytes + 2 * ids_bytes + 2 * cid_bytes + cc_bytes + part_bytes + hist_bytes + state_bytes, 2);
+    if (!base)
+        return FX_ENOMEM;
+    RaggedLists L;
+    unsigned char *p = base;
+    L.counts = (int32_t *)p, p += counts_bytes;
+    L.reg_ids = (int32_t *)p, p += ids_bytes;
+    L.lds_ids = (int32_t *)p, p += ids_bytes;
+    L.cloud_ids = (int32_t *)p, p += cid_bytes;
+    L.cloud_first = (int32_t *)p, p += cid_bytes;
+    L.chunk_cloud = (int32_t *)p, p += cc_bytes;
+    L.max_clouds = max_clouds;
+    L.max_chunks = max_chunks;
+    CloudWork Wk;
+    Wk.cloud_ids = L.cloud_ids;
+    Wk.cloud_first = L.cloud_first;
+    Wk.chunk_cloud = L.chunk_cloud;
+    Wk.part = (double *)p, p += part_bytes;
+    Wk.hpart = (uint32_t *)p, p += hist_bytes;
+    Wk.state = (double *)p;
+    Wk.n_chunks_dev = L.counts + 3;
+    Wk.n_clouds_dev = L.counts + 2;
+
+    FX_HIP_CHECK(hipMemsetAsync(L.counts, 0, counts_bytes, s));
+    const int64_t reg_max = A.dims == 3 ? REG_SET_MAX_POINTS : -1;   // 2-D sets take the LDS kernel
+    hipLaunchKernelGGL(pca_classify_kernel, dim3((unsigned)((B + FX_BLOCK - 1) / FX_BLOCK)), dim3(FX_BLOCK), 0, s, A, L, B,
+                       reg_max);
+    FX_HIP_CHECK(hipGetLastError());
+    FxProfileScope prof(s);
+    int rc = FX_OK;
+    if (A.dims == 3) {
+        PcaArgs S = A;
+        S.set_ids = L.reg_ids;
+        S.n_sets = B;                 // sizes the grid; the kernel reads the true count
+        S.n_sets_dev = L.counts + 0;
+        rc = launch_reg_sets(S, REG_SET_MAX_POINTS, true, s);
+    }
+    if (rc == FX_OK) {
+        PcaArgs S = A;
+        S.set_ids = L.lds_ids;
+        S.n_sets = B;
+        S.n_sets_dev = L.counts + 1;
+        rc = launch_small_sets(S, WAVE_SET_MAX_POINTS, s);
+    }
+    if (rc != FX_OK || max_clouds == 0)
+        return rc;
+    hipLaunchKernelGGL(pca_cloud_scan_kernel, dim3(1), dim3(1024), 0, s, A, L);
+    hipLaunchKernelGGL(pca_chunk_fill_kernel, dim3((unsigned)(max_clouds < 65536 ? (max_clouds + FX_BLOCK - 1) / FX_BLOCK : 256)),
+                       dim3(FX_BLOCK), 0, s, L);
+    const dim3 grid((unsigned)(max_chunks < 2048 ? max_chunks : 2048)), block(CLOUD_THREADS);
+    hipLaunchKernelGGL(cloud_sum_kernel, grid, block, 0, s, A, Wk);
+    if (A.normalize)
+        hipLaunchKernelGGL(cloud_moment_kernel<0>, grid, block, 0, s, A, Wk);
+    hipLaunchKernelGGL(cloud_moment_kernel<1>, grid, block, 0, s, A, Wk);
+    hipLaunchKernelGGL(cloud_proj_kernel, grid, block, 0, s, A, Wk);
+    hipLaunchKernelGGL(cloud_hist_kernel, grid, block, 0, s, A, Wk);
+    hipLaunchKernelGGL(cloud_finish_kernel, dim3((unsigned)(max_clouds < 1024 ? max_clouds : 1024)), dim3(FX_BLOCK), 0, s, A,
+                       Wk);
     FX_HIP_CHECK(hipGetLastError());
     return FX_OK;
 }
@@ -1288,6 +1528,7 @@ extern "C" int fx_pca_batch_f32(const float *d_pts, const int64_t *d_offsets, in
     A.out = d_out;
     A.eig = d_eig;
     A.slab_floats = 0;
+    A.n_sets_dev = nullptr;
     FxCallGuard guard(s);
 
     if (!d_offsets) {
@@ -1315,7 +1556,10 @@ extern "C" int fx_pca_batch_f32(const float *d_pts, const int64_t *d_offsets, in
         return rc;
     }
 
-    // Ragged batch: read the offsets back once, route small sets to the LDS
+    // Ragged batch.  With the caller's point count the work lists are built on the device and nothing waits.
+    if (N > 0)
+        return launch_ragged_on_device(A, B, N, guard);
+    // Without it: read the offsets back once, route small sets to the LDS
     // kernel and large clouds to the streaming kernel.
     int64_t *h_off = (int64_t *)malloc((size_t)(B + 1) * sizeof(int64_t));
     if (!h_off) {

@@ -232,7 +232,7 @@ def pca_batch(points: torch.Tensor, offsets: Optional[torch.Tensor] = None, n_bi
         if points.dim() != 2 or offsets.dtype != torch.int64 or offsets.dim() != 1:
             raise ValueError("ragged input needs points [total, D] and int64 offsets [B+1]")
         offsets = offsets.contiguous()
-        B, N, D = offsets.numel() - 1, 0, points.shape[1]
+        B, N, D = offsets.numel() - 1, int(points.shape[0]), points.shape[1]   # N = points behind the pointer
         off_ptr = offsets.data_ptr()
     res = {"out": torch.empty((B, 9 + int(n_bins)), dtype=torch.float32, device=points.device)}
     if eig:

@@ -279,8 +279,10 @@ def _log_error(reports_dir: Path, sample_path: Path, e: Exception) -> None:
 
 def render_samples(tasks: Sequence[Tuple]) -> List[Dict[str, Any]]:
     """The reference's render_sample_worker (:422-505) for a batch of task
-    tuples that share the rendering settings: files are read on the host, all
-    views that have to be drawn are rendered in one device call, PNGs written."""
+    tuples: files are read on the host, the views that have to be drawn are
+    rendered in one device call per distinct rendering settings, PNGs written.
+    A sample that fails at any step is logged and gets a "failed: ..." record;
+    the others are unaffected."""
     from PIL import Image
     results: List[Optional[Dict[str, Any]]] = [None] * len(tasks)
     loaded = []
@@ -301,26 +303,53 @@ def render_samples(tasks: Sequence[Tuple]) -> List[Dict[str, Any]]:
             _log_error(Path(reports_dir_str), sample_path, e)
             rec["note"], rec["rendered_timestamp"] = f"failed: {e}", _now()
             results[k] = {"success": False, "record": rec, "saved_paths": []}
+    # the reference catches every exception per sample, logs it and returns a "failed: ..." record
+    # (:442-498): one bad cloud, marker size or unwritable path must not take the batch with it
+    failed: Dict[int, Exception] = {}
     todo = [item for item in loaded if item[3]]
-    if todo:
-        _, _, resolution, views, point_size, bg_color, transparent, _, radius_factor, seed, _, _ = tasks[todo[0][0]]
-        imgs = render_views_batch([item[1] for item in todo], views, resolution, point_size, bg_color, radius_factor,
-                                  seed).cpu().numpy()
-        # PNG encoding is the slow part of a run (zlib on the host): on the ingest thread pool
-        from . import ingest
+    groups: Dict[tuple, list] = {}
+    for item in todo:   # one device call per distinct rendering settings
+        _, _, resolution, views, point_size, bg_color, transparent, _, radius_factor, seed, _, _ = tasks[item[0]]
+        groups.setdefault((resolution, views, point_size, bg_color, transparent, radius_factor, seed), []).append(item)
+    from . import ingest
+    for (resolution, views, point_size, bg_color, transparent, radius_factor, seed), items in groups.items():
+        def render(batch):
+            return render_views_batch([it[1] for it in batch], views, resolution, point_size, bg_color, radius_factor,
+                                      seed).cpu().numpy()
+        stacks: Dict[int, np.ndarray] = {}
+        try:
+            for it, stack in zip(items, render(items)):
+                stacks[it[0]] = stack
+        except Exception:
+            for it in items:   # find the sample(s) at fault: cloud by cloud
+                try:
+                    stacks[it[0]] = render([it])[0]
+                except Exception as e:
+                    failed[it[0]] = e
 
+        # PNG encoding is the slow part of a run (zlib on the host): on the ingest thread pool
         def write(job):
             gray, path = job
             rgb = Image.fromarray(np.repeat(gray[:, :, None], 3, axis=2), mode="RGB")
             save_image(rgb if bg_color == "white" else rgb.convert("RGBA"), path, transparent)
 
-        jobs = [(stack[v], item[2][v]) for item, stack in zip(todo, imgs) for v in item[3]]
-        for ok, err in ingest.map_ordered(write, jobs, ingest.default_workers()):
-            if not ok:
-                raise err
+        jobs, owner = [], []
+        for it in items:
+            if it[0] in stacks:
+                for v in it[3]:
+                    jobs.append((stacks[it[0]][v], it[2][v]))
+                    owner.append(it[0])
+        for k, (ok, err) in zip(owner, ingest.map_ordered(write, jobs, ingest.default_workers())):
+            if not ok and k not in failed:
+                failed[k] = err
     for k, pts, names, need, rec in loaded:
-        rec["views_dir"], rec["n_views"] = str(names[0].parent.resolve()), len(names)
-        rec["note"], rec["rendered_timestamp"] = "ok", _now()
+        rec["rendered_timestamp"] = _now()
+        if k in failed:
+            _log_error(Path(tasks[k][11]), Path(tasks[k][0]), failed[k])
+            rec["note"] = f"failed: {failed[k]}"
+            results[k] = {"success": False, "record": rec, "saved_paths": []}
+            continue
+        rec["views_dir"], rec["n_views"], rec["note"] = str(names[0].parent.resolve()), len(names), "ok"
         results[k] = {"success": True, "record": rec, "saved_paths": [str(p) for p in names]}
     return results  # type: ignore[return-value]
 

@@ -138,16 +138,19 @@ int fx_hu_groupstat(const float *d_hulog7, const int64_t *d_group_offsets,
  *
  *   d_pts       points, `dims` floats each (2 or 3; z = 0 when dims == 2)
  *   d_offsets   NULL: B sets of exactly N points, set b at point b*N;
- *               else B+1 point offsets on the device (CSR), N ignored
+ *               else B+1 point offsets on the device (CSR), and N = the number
+ *               of points behind d_pts (any upper bound of d_offsets[B]): the
+ *               work lists are then built on the device and the call does not
+ *               wait for the stream.  N <= 0: unknown; the call copies the
+ *               offsets to the host and waits for `stream` once before
+ *               launching (and rejects decreasing offsets with FX_EINVAL,
+ *               which the device path turns into NaN rows)
  *   n_bins      1..64 bins of the |projection on PC1| histogram
  *   normalize   != 0: divide centred points by their largest norm (:79-83)
  *   d_out       B x (9+n_bins) floats: lambda1..3, r1..3, ratio12, ratio23,
  *               trace, histogram.  Sets with fewer than 3 points give a NaN
  *               row (the reference function raises ValueError, :72-73).
  *   d_eig       optional, B x 6 doubles (lambda1..3, v1) before the cast.
- *
- * With d_offsets != NULL the call copies the offsets to the host and waits
- * for `stream` once before launching.
  */
 int fx_pca_batch_f32(const float *d_pts, const int64_t *d_offsets, int64_t B,
                      int64_t N, int dims, int n_bins, int normalize,

@@ -1,6 +1,8 @@
 """View renderer on the device against views drawn by the reference's own
 render_fallback_matplotlib (golden: matplotlib's Agg output) and against the
 oracle's restatement on seeded clouds: identical pixels."""
+from pathlib import Path
+
 import numpy as np
 import pytest
 import torch
@@ -118,3 +120,41 @@ def test_directory_run_and_views_feed_the_hu_path(gpu, tmp_path, oracle):
     mins, maxs, cen, _ = oracle.bbox_and_center(clouds["Eiche_2"].astype(np.float64))
     pose = oracle.compute_camera_poses(6, mins, maxs, cen)[3]
     np.testing.assert_array_equal(batch[3], oracle.render_view(clouds["Eiche_2"].astype(np.float64), pose, 128, rv.marker_stamp(2.0)))
+
+
+def test_one_bad_sample_does_not_take_the_batch_with_it(gpu, tmp_path):
+    """The reference's worker catches per sample: a cloud the renderer refuses
+    (NaN coordinates, a marker size without a stamp) or a file that cannot be
+    read gets a "failed: ..." record and a line in read_errors.log; every other
+    sample of the batch is rendered and gets its manifest row."""
+    rv = pkg("render_views")
+    rng = np.random.default_rng(5)
+    sampled, out, reports = tmp_path / "sampled", tmp_path / "views", tmp_path / "reports"
+    sampled.mkdir()
+    good = [rng.normal(size=(300, 3)).astype(np.float32) for _ in range(3)]
+    np.save(sampled / "a_good.npy", good[0])
+    np.save(sampled / "b_empty.npy", np.zeros((0, 3), np.float32))          # fails at load time
+    np.save(sampled / "c_good.npy", good[1])
+    (sampled / "d_broken.npy").write_bytes(b"not an npy file")              # fails at load time
+    np.save(sampled / "e_good.npy", good[2])
+    common = (str(out), 96, 4, 2.0, "white", False, False, 2.0, 42, True, str(reports))
+    tasks = [(str(p),) + common for p in sorted(sampled.glob("*.npy"))]
+    # a task with a marker size that has no stamp: fails on the device side of the batch
+    tasks.append((str(sampled / "a_good.npy"), str(tmp_path / "views2"), 96, 4, 2.37, "white", False, False, 2.0, 42, True,
+                  str(reports)))
+    res = rv.render_samples(tasks)
+    assert [r["success"] for r in res] == [True, False, True, False, True, False]
+    assert all(r["record"]["note"] == "ok" for r in res if r["success"])
+    assert all(r["record"]["note"].startswith("failed: ") for r in res if not r["success"])
+    for r in res:
+        if r["success"]:
+            assert len(r["saved_paths"]) == 4 and all(Path(p).exists() for p in r["saved_paths"])
+    log = (reports / "read_errors.log").read_text().splitlines()
+    assert len(log) == 3 and all(len(ln.split("\t")) == 3 for ln in log)
+    # the script still writes a manifest row for every sample
+    rc = rv.main(["--sampled_dir", str(sampled), "--out_dir", str(out), "--views", "4", "--resolution", "96",
+                  "--reports_dir", str(reports), "--overwrite", "--n_preview", "0"])
+    assert rc == 0
+    import pandas as pd
+    man = pd.read_csv(out / "manifest_views.csv")
+    assert len(man) == 5 and sorted(man["note"].str.startswith("failed").tolist()) == [False, False, False, True, True]
