@@ -670,58 +670,95 @@ __device__ SilRuns sil_label(const uint32_t *m, int rows, int wc, int wpr, bool 
         R.val[r] = 0u;
     }
     __syncthreads();
-    for (int wi = t + wc; wi < nw; wi += FX_BLOCK) {
-        const int y = wi / wc, w = wi - y * wc;
-        const uint32_t *row = m + y * wpr, *above = row - wpr;
-        const uint32_t cur = row[w], u = above[w];
-        if (!cur)
-            continue;
-        const uint32_t mp = w > 0 ? row[w - 1] : 0u, up = w > 0 ? above[w - 1] : 0u;
-        const uint32_t sm = cur & ~((cur << 1) | (mp >> 31)), su = u & ~((u << 1) | (up >> 31));
-        const uint32_t pm = pre[wi], pu = pre[wi - wc];
-        const uint32_t o = cur & u, op = mp & up;
-        uint32_t os = o & ~((o << 1) | (op >> 31));  // first pixel of every stretch of overlap
-        while (os) {
-            const int bit = __ffs((int)os) - 1;
-            os &= os - 1;
-            const uint32_t le = sil_le(bit);
-            sil_unite(parent, pm + __popc(sm & le) - 1u, pu + __popc(su & le) - 1u);
-        }
-        if (conn8) {
-            const uint32_t mn = w + 1 < wc ? row[w + 1] : 0u, un = w + 1 < wc ? above[w + 1] : 0u;
-            const uint32_t mL = (cur << 1) | (mp >> 31), mR = (cur >> 1) | (mn << 31);
-            const uint32_t uL = (u << 1) | (up >> 31), uR = (u >> 1) | (un << 31);
-            uint32_t dl = cur & ~mL & uL & ~u;  // a run starts here; the row above has the pixel to the left only
-            uint32_t dr = cur & ~mR & uR & ~u;  // a run ends here; the row above has the pixel to the right only
-            while (dl) {
-                const int bit = __ffs((int)dl) - 1;
-                dl &= dl - 1;
-                sil_unite(parent, pm + __popc(sm & sil_le(bit)) - 1u, sil_run_at(m, pre, y - 1, 32 * w + bit - 1, wc, wpr));
+    // Two rounds.  First every run is hung below the run above its first contact (a plain store: only this
+    // thread writes the run's parent), which leaves chains as long as the shape is tall; pointer jumping
+    // flattens them.  Then the remaining contacts (a run that touches several runs above) are united on the
+    // flat forest, where a root is one step away, and the few new links are flattened again.  Uniting
+    // everything at once instead makes single threads climb chains of hundreds of links: a run below a
+    // tall shape that joins the background on its left to the background on its right.
+    auto contacts = [&](bool first_round) {
+        for (int wi = t + wc; wi < nw; wi += FX_BLOCK) {
+            const int y = wi / wc, w = wi - y * wc;
+            const uint32_t *row = m + y * wpr, *above = row - wpr;
+            const uint32_t cur = row[w], u = above[w];
+            if (!cur)
+                continue;
+            const uint32_t mp = w > 0 ? row[w - 1] : 0u, up = w > 0 ? above[w - 1] : 0u;
+            const uint32_t sm = cur & ~((cur << 1) | (mp >> 31)), su = u & ~((u << 1) | (up >> 31));
+            const uint32_t pm = pre[wi], pu = pre[wi - wc];
+            auto link = [&](uint32_t a, uint32_t b) {   // run a of this row touches run b of the row above
+                if (first_round) {
+                    // the first contact of a run in raster order: the lowest position claims the run
+                    atomicMin(&R.val[a], b);
+                } else if (R.val[a] != b) {
+                    sil_unite(parent, a, b);
+                }
+            };
+            const uint32_t o = cur & u, op = mp & up;
+            uint32_t os = o & ~((o << 1) | (op >> 31));  // first pixel of every stretch of overlap
+            while (os) {
+                const int bit = __ffs((int)os) - 1;
+                os &= os - 1;
+                const uint32_t le = sil_le(bit);
+                link(pm + __popc(sm & le) - 1u, pu + __popc(su & le) - 1u);
             }
-            while (dr) {
-                const int bit = __ffs((int)dr) - 1;
-                dr &= dr - 1;
-                sil_unite(parent, pm + __popc(sm & sil_le(bit)) - 1u, sil_run_at(m, pre, y - 1, 32 * w + bit + 1, wc, wpr));
+            if (conn8) {
+                const uint32_t mn = w + 1 < wc ? row[w + 1] : 0u, un = w + 1 < wc ? above[w + 1] : 0u;
+                const uint32_t mL = (cur << 1) | (mp >> 31), mR = (cur >> 1) | (mn << 31);
+                const uint32_t uL = (u << 1) | (up >> 31), uR = (u >> 1) | (un << 31);
+                uint32_t dl = cur & ~mL & uL & ~u;  // a run starts here; the row above has the pixel to the left only
+                uint32_t dr = cur & ~mR & uR & ~u;  // a run ends here; the row above has the pixel to the right only
+                while (dl) {
+                    const int bit = __ffs((int)dl) - 1;
+                    dl &= dl - 1;
+                    link(pm + __popc(sm & sil_le(bit)) - 1u, sil_run_at(m, pre, y - 1, 32 * w + bit - 1, wc, wpr));
+                }
+                while (dr) {
+                    const int bit = __ffs((int)dr) - 1;
+                    dr &= dr - 1;
+                    link(pm + __popc(sm & sil_le(bit)) - 1u, sil_run_at(m, pre, y - 1, 32 * w + bit + 1, wc, wpr));
+                }
             }
         }
-    }
+    };
+    auto flatten = [&]() {
+        // every run to its root: pointer jumping, the depth halves per round
+        for (;;) {
+            int changed = 0;
+            for (int r = t; r < R.n; r += FX_BLOCK) {
+                const uint32_t q = ((volatile uint32_t *)parent)[r];
+                const uint32_t g = ((volatile uint32_t *)parent)[q];
+                if (g != q) {
+                    parent[r] = g;
+                    changed = 1;
+                }
+            }
+            __threadfence_block();
+            if (!__syncthreads_or(changed))
+                break;
+        }
+    };
+    // round one: val[] (still free) collects, per run, the smallest run index it touches above
+    for (int r = t; r < R.n; r += FX_BLOCK)
+        R.val[r] = 0xFFFFFFFFu;
+    __syncthreads();
+    contacts(true);
     __threadfence_block();
     __syncthreads();
-    // every run to its root: pointer jumping, the depth halves per round
-    for (;;) {
-        int changed = 0;
-        for (int r = t; r < R.n; r += FX_BLOCK) {
-            const uint32_t q = ((volatile uint32_t *)parent)[r];
-            const uint32_t g = ((volatile uint32_t *)parent)[q];
-            if (g != q) {
-                parent[r] = g;
-                changed = 1;
-            }
-        }
-        __threadfence_block();
-        if (!__syncthreads_or(changed))
-            break;
-    }
+    for (int r = t; r < R.n; r += FX_BLOCK)
+        if (R.val[r] != 0xFFFFFFFFu)
+            parent[r] = R.val[r];
+    __threadfence_block();
+    __syncthreads();
+    flatten();
+    // round two: the other contacts
+    contacts(false);
+    __threadfence_block();
+    __syncthreads();
+    flatten();
+    for (int r = t; r < R.n; r += FX_BLOCK)
+        R.val[r] = 0u;
+    __syncthreads();
     return R;
 }
 
