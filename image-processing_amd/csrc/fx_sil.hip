@@ -418,21 +418,53 @@ __global__ __launch_bounds__(FX_WAVE) void sil_otsu_cv_kernel(const uint32_t *hi
 }
 
 // ------------------------------------------------------------ mask kernel
+// Division of small non-negative numbers (below 2^23) by a block-uniform divisor of at most 512 that is not
+// known at compile time: a multiplication by ceil(2^32 / d) instead of the twenty-odd instructions of a
+// 32-bit division, which the word loops below would otherwise pay once per mask word and pass.
+struct SilDiv {
+    uint32_t d, magic;
+};
+__device__ __forceinline__ SilDiv sil_div_make(int d)
+{
+    SilDiv v;
+    v.d = (uint32_t)d;
+    v.magic = d > 1 ? 0xFFFFFFFFu / (uint32_t)d + 1u : 0u;
+    return v;
+}
+__device__ __forceinline__ int sil_div(int n, SilDiv v) { return v.d > 1 ? (int)__umulhi((uint32_t)n, v.magic) : n; }
+
+// Word loops of a rows x cols bit mask: words per row, and for the morphology passes the split into
+// strips of `rs` rows of one word column per thread.
+struct SilGeom {
+    int rows, cols, wc, strips, rs;
+    SilDiv dv;
+};
+__device__ __forceinline__ SilGeom sil_geom(int rows, int cols)
+{
+    SilGeom g;
+    g.rows = rows;
+    g.cols = cols;
+    g.wc = (cols + 31) >> 5;
+    g.dv = sil_div_make(g.wc);
+    g.strips = FX_BLOCK / g.wc;
+    g.strips = g.strips < 1 ? 1 : g.strips;
+    g.rs = (rows + g.strips - 1) / g.strips;
+    return g;
+}
+
 // 3x3 dilation or erosion of a bit mask, scipy.ndimage semantics with
 // border_value = 0: whatever lies outside the rows x cols rectangle is
 // background for both operations.  Bits at or beyond `cols` stay zero.
 template <bool DILATE>
-__device__ void sil_morph(const uint32_t *s, uint32_t *d, int rows, int cols, int wpr)
+__device__ void sil_morph(const uint32_t *s, uint32_t *d, const SilGeom &G, int wpr)
 {
-    const int wc = (cols + 31) >> 5;
+    const int rows = G.rows, cols = G.cols, wc = G.wc;
     const uint32_t lastmask = (cols & 31) ? ((1u << (cols & 31)) - 1u) : ~0u;
     // strips of `rs` rows of one word column per thread: a row's horizontal
     // combination is computed once and used for three output rows
-    int strips = FX_BLOCK / wc;
-    strips = strips < 1 ? 1 : strips;
-    const int rs = (rows + strips - 1) / strips;
+    const int strips = G.strips, rs = G.rs;
     for (int it = threadIdx.x; it < wc * strips; it += FX_BLOCK) {
-        const int w = it % wc, y0 = (it / wc) * rs;
+        const int sy = sil_div(it, G.dv), w = it - sy * wc, y0 = sy * rs;
         if (y0 >= rows)
             continue;
         const int y1 = y0 + rs < rows ? y0 + rs : rows;
@@ -466,16 +498,14 @@ __device__ void sil_morph(const uint32_t *s, uint32_t *d, int rows, int cols, in
 // i.e. they count as foreground for an erosion and as background for a
 // dilation.  Bits at or beyond `cols` are zero in the result.
 template <bool DILATE, bool FIVE>
-__device__ void sil_morph_cv(const uint32_t *s, uint32_t *d, int rows, int cols, int wpr)
+__device__ void sil_morph_cv(const uint32_t *s, uint32_t *d, const SilGeom &G, int wpr)
 {
-    const int wc = (cols + 31) >> 5;
+    const int rows = G.rows, cols = G.cols, wc = G.wc;
     const uint32_t lastmask = (cols & 31) ? ((1u << (cols & 31)) - 1u) : ~0u;
     const uint32_t fill = DILATE ? 0u : ~0u;
-    int strips = FX_BLOCK / wc;
-    strips = strips < 1 ? 1 : strips;
-    const int rs = (rows + strips - 1) / strips;
+    const int strips = G.strips, rs = G.rs;
     for (int it = threadIdx.x; it < wc * strips; it += FX_BLOCK) {
-        const int w = it % wc, y0 = (it / wc) * rs;
+        const int sy = sil_div(it, G.dv), w = it - sy * wc, y0 = sy * rs;
         if (y0 >= rows)
             continue;
         const int y1 = y0 + rs < rows ? y0 + rs : rows;
@@ -612,7 +642,7 @@ struct SilRuns {
 // of neighbouring rows that touch (sharing a column, or for CONN8 also
 // diagonally) are united lock-free, then every run is pointed at its root.
 // Every thread of the block calls this; the result is block-uniform.
-__device__ SilRuns sil_label(const uint32_t *m, int rows, int wc, int wpr, bool conn8, uint32_t *pre, uint32_t *s_scan,
+__device__ SilRuns sil_label(const uint32_t *m, int rows, int wc, SilDiv dv, int wpr, bool conn8, uint32_t *pre, uint32_t *s_scan,
                              int *s_nruns, uint32_t *lds_runs, uint32_t *glob_runs, int run_cap)
 {
     const int t = threadIdx.x;
@@ -624,7 +654,7 @@ __device__ SilRuns sil_label(const uint32_t *m, int rows, int wc, int wpr, bool 
         for (int j = 0; j < per; j++) {
             const int wi = t * per + j;
             if (wi < nw) {
-                const int y = wi / wc, w = wi - y * wc;
+                const int y = sil_div(wi, dv), w = wi - y * wc;
                 local += __popc(sil_starts(m + y * wpr, w));
             }
         }
@@ -651,7 +681,7 @@ __device__ SilRuns sil_label(const uint32_t *m, int rows, int wc, int wpr, bool 
         for (int j = 0; j < per; j++) {
             const int wi = t * per + j;
             if (wi < nw) {
-                const int y = wi / wc, w = wi - y * wc;
+                const int y = sil_div(wi, dv), w = wi - y * wc;
                 pre[wi] = base;
                 base += __popc(sil_starts(m + y * wpr, w));
             }
@@ -678,7 +708,7 @@ __device__ SilRuns sil_label(const uint32_t *m, int rows, int wc, int wpr, bool 
     // tall shape that joins the background on its left to the background on its right.
     auto contacts = [&](bool first_round) {
         for (int wi = t + wc; wi < nw; wi += FX_BLOCK) {
-            const int y = wi / wc, w = wi - y * wc;
+            const int y = sil_div(wi, dv), w = wi - y * wc;
             const uint32_t *row = m + y * wpr, *above = row - wpr;
             const uint32_t cur = row[w], u = above[w];
             if (!cur)
@@ -781,9 +811,12 @@ __device__ __forceinline__ void sil_for_segments(const uint32_t *m, const uint32
 }
 
 #ifdef SIL_TIMING
+#ifndef SIL_TICK_IMG
+#define SIL_TICK_IMG 0
+#endif
 #define SIL_TICK(n)                                        \
     do {                                                   \
-        if (t == 0 && blockIdx.x == 0 && b == 0)           \
+        if (t == 0 && blockIdx.x == 0 && b == SIL_TICK_IMG) \
             s_tick[n] = __builtin_readcyclecounter();      \
     } while (0)
 #else
@@ -815,7 +848,7 @@ __device__ __forceinline__ void sil_box_reduce(int mnx, int mny, int mxx, int mx
     }
 }
 
-__global__ __launch_bounds__(FX_BLOCK) void sil_mask_kernel(SilArgs A)
+__global__ __launch_bounds__(FX_BLOCK, 4) void sil_mask_kernel(SilArgs A)
 {
     extern __shared__ __align__(16) uint8_t sil_smem[];
     __shared__ double s_between[FX_WAVES_PER_BLOCK];
@@ -837,6 +870,8 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_mask_kernel(SilArgs A)
     const int H = A.H, W = A.W, wpr = A.wpr, res = A.res;
     const int wcH = (W + 31) >> 5;
     const uint32_t lastH = (W & 31) ? ((1u << (W & 31)) - 1u) : ~0u;
+    const SilGeom GH = sil_geom(H, W);
+    const SilDiv dvV = sil_div_make((W + 32) >> 5), dvP = sil_div_make(res >> 4);
 
     for (int64_t b = blockIdx.x; b < A.B; b += gridDim.x) {
         __syncthreads();
@@ -938,7 +973,7 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_mask_kernel(SilArgs A)
                         const int wi = w0 + j * FX_BLOCK;
                         q[j][0] = q[j][1] = make_uint4(0u, 0u, 0u, 0u);
                         if (wi < H * wcH) {
-                            const int y = wi / wcH, w = wi - y * wcH;
+                            const int y = sil_div(wi, GH.dv), w = wi - y * wcH;
                             const uint8_t *p = blur + (int64_t)y * W + 32 * w;
                             q[j][0] = *(const uint4 *)p;
                             if (32 * w + 16 < W)
@@ -949,7 +984,7 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_mask_kernel(SilArgs A)
                     for (int j = 0; j < 4; j++) {
                         const int wi = w0 + j * FX_BLOCK;
                         if (wi < H * wcH) {
-                            const int y = wi / wcH, w = wi - y * wcH;
+                            const int y = sil_div(wi, GH.dv), w = wi - y * wcH;
                             uint32_t word = 0;
                             if (kcmp <= 255u) {
 #pragma unroll
@@ -966,7 +1001,7 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_mask_kernel(SilArgs A)
                 }
             } else {
                 for (int wi = t; wi < H * wcH; wi += FX_BLOCK) {
-                    const int y = wi / wcH, w = wi - y * wcH;
+                    const int y = sil_div(wi, GH.dv), w = wi - y * wcH;
                     const uint8_t *p = blur + (int64_t)y * W + 32 * w;
                     uint32_t word = 0;
                     for (int k = 0; k < 32 && 32 * w + k < W; k++)
@@ -986,7 +1021,7 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_mask_kernel(SilArgs A)
         const bool inverted = 2ll * s_v[SV_COUNT] > (long long)H * W;
         if (inverted) {
             for (int wi = t; wi < H * wcH; wi += FX_BLOCK) {
-                const int y = wi / wcH, w = wi - y * wcH;
+                const int y = sil_div(wi, GH.dv), w = wi - y * wcH;
                 uint32_t word = ~mA[y * wpr + w];
                 if (w == wcH - 1)
                     word &= lastH;
@@ -998,16 +1033,16 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_mask_kernel(SilArgs A)
         SIL_TICK(2);
         if (!cv) {
             // ---- 3x3 closing then opening (reference :170-186, scipy.ndimage branch)
-            sil_morph<true>(mA, mB, H, W, wpr);
-            sil_morph<false>(mB, mA, H, W, wpr);
-            sil_morph<false>(mA, mB, H, W, wpr);
-            sil_morph<true>(mB, mA, H, W, wpr);
+            sil_morph<true>(mA, mB, GH, wpr);
+            sil_morph<false>(mB, mA, GH, wpr);
+            sil_morph<false>(mA, mB, GH, wpr);
+            sil_morph<true>(mB, mA, GH, wpr);
 
             SIL_TICK(3);
             // ---- bounding box of the foreground (reference :209-214, branch without cv2)
             int mnx = W, mny = H, mxx = -1, mxy = -1;
             for (int wi = t; wi < H * wcH; wi += FX_BLOCK) {
-                const int y = wi / wcH, w = wi - y * wcH;
+                const int y = sil_div(wi, GH.dv), w = wi - y * wcH;
                 const uint32_t m = mA[y * wpr + w];
                 if (m) {
                     const int lo = 32 * w + __ffs((int)m) - 1, hi = 32 * w + 31 - __clz((int)m);
@@ -1021,23 +1056,25 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_mask_kernel(SilArgs A)
         } else {
             // ---- cv2.morphologyEx with the 5x5 ellipse: close, iterations = 2 (dilate, dilate, erode, erode),
             // then open (erode, dilate) (reference :171-177)
-            sil_morph_cv<true, true>(mA, mB, H, W, wpr);
-            sil_morph_cv<true, true>(mB, mA, H, W, wpr);
-            sil_morph_cv<false, true>(mA, mB, H, W, wpr);
-            sil_morph_cv<false, true>(mB, mA, H, W, wpr);
-            sil_morph_cv<false, true>(mA, mB, H, W, wpr);
-            sil_morph_cv<true, true>(mB, mA, H, W, wpr);
+            sil_morph_cv<true, true>(mA, mB, GH, wpr);
+            sil_morph_cv<true, true>(mB, mA, GH, wpr);
+            sil_morph_cv<false, true>(mA, mB, GH, wpr);
+            sil_morph_cv<false, true>(mB, mA, GH, wpr);
+            sil_morph_cv<false, true>(mA, mB, GH, wpr);
+            sil_morph_cv<true, true>(mB, mA, GH, wpr);
 
             SIL_TICK(3);
             // ---- box of the external contour with the largest contourArea (reference :198-221).
             // (1) background runs, 4-connected; those that reach the image frame are the outside
             for (int wi = t; wi < H * wcH; wi += FX_BLOCK) {
-                const int y = wi / wcH, w = wi - y * wcH;
+                const int y = sil_div(wi, GH.dv), w = wi - y * wcH;
                 mB[y * wpr + w] = ~mA[y * wpr + w] & (w == wcH - 1 ? lastH : ~0u);
             }
-            SilRuns bg = sil_label(mB, H, wcH, wpr, false, pre, s_scan, &s_v[SV_NRUNS], s_runs, glob_runs, A.run_cap);
+            SIL_TICK(14);
+            SilRuns bg = sil_label(mB, H, wcH, GH.dv, wpr, false, pre, s_scan, &s_v[SV_NRUNS], s_runs, glob_runs, A.run_cap);
+            SIL_TICK(15);
             for (int wi = t; wi < H * wcH; wi += FX_BLOCK) {
-                const int y = wi / wcH, w = wi - y * wcH;
+                const int y = sil_div(wi, GH.dv), w = wi - y * wcH;
                 sil_for_segments(mB, pre, y, w, wcH, wpr, [&](uint32_t seg, uint32_t id) {
                     const bool frame = y == 0 || y == H - 1 || (w == 0 && (seg & 1u)) ||
                                        (w == wcH - 1 && ((seg >> ((W - 1) & 31)) & 1u));
@@ -1050,7 +1087,7 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_mask_kernel(SilArgs A)
             // (2) holes filled: components nested inside a hole vanish, outer borders stay as they are.  The
             // complement is taken from mA again because mB is being overwritten.
             for (int wi = t; wi < H * wcH; wi += FX_BLOCK) {
-                const int y = wi / wcH, w = wi - y * wcH;
+                const int y = sil_div(wi, GH.dv), w = wi - y * wcH;
                 const uint32_t m = mA[y * wpr + w];
                 uint32_t comp = ~m & (w == wcH - 1 ? lastH : ~0u), holes = 0u;
                 if (comp) {
@@ -1069,43 +1106,61 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_mask_kernel(SilArgs A)
                 mB[y * wpr + w] = m | holes;
             }
             // (3) 8-connected components of the filled mask = the external contours
-            SilRuns fg = sil_label(mB, H, wcH, wpr, true, pre, s_scan, &s_v[SV_NRUNS], s_runs, glob_runs, A.run_cap);
+            SIL_TICK(16);
+            SilRuns fg = sil_label(mB, H, wcH, GH.dv, wpr, true, pre, s_scan, &s_v[SV_NRUNS], s_runs, glob_runs, A.run_cap);
             // (4) twice the signed area inside each outer border, as a sum over the corners of the pixel grid:
             // the border follower steps between the two foreground pixels of a straight corner and cuts across
             // the background pixel of a concave corner; saddle corners give two opposite steps that cancel.
+            // Summed as (qy - py) * (qx + px) over the steps p -> q, which over a closed border equals the
+            // shoelace sum and to which steps along a row contribute nothing.  A step goes up (qy = py - 1)
+            // exactly when both pixels left of the corner are set, and down otherwise.
+            SIL_TICK(17);
             const int wcV = (W + 32) >> 5;  // corners x = 0 .. W
+            uint32_t acc_root = 0xFFFFFFFFu, acc = 0u;  // a thread's corners mostly lie on one border
             for (int vi = t; vi < (H + 1) * wcV; vi += FX_BLOCK) {
-                const int vy = vi / wcV, w = vi - vy * wcV;
+                const int vy = sil_div(vi, dvV), w = vi - vy * wcV;
                 const uint32_t *ru = mB + (vy - 1) * wpr, *rd = mB + vy * wpr;
                 const uint32_t up = vy > 0 && w < wcH ? ru[w] : 0u, upp = vy > 0 && w > 0 ? ru[w - 1] : 0u;
                 const uint32_t dn = vy < H && w < wcH ? rd[w] : 0u, dnp = vy < H && w > 0 ? rd[w - 1] : 0u;
+                // pixels around the corner (vx, vy): a = (vx-1, vy-1), b = (vx, vy-1), c = (vx-1, vy), d = (vx, vy)
                 const uint32_t ca = (up << 1) | (upp >> 31), cb = up, cc = (dn << 1) | (dnp >> 31), cd = dn;
-                uint32_t act = (ca & cb & ~cc & ~cd) | (cc & cd & ~ca & ~cb) | (ca & cc & ~cb & ~cd) | (cb & cd & ~ca & ~cc) |
-                               (ca & cb & cc & ~cd) | (ca & cb & cd & ~cc) | (ca & cc & cd & ~cb) | (cb & cc & cd & ~ca);
+                const uint32_t vert = (ca & cc & ~cb & ~cd) | (cb & cd & ~ca & ~cc);
+                const uint32_t conc = (ca & cb & cc & ~cd) | (ca & cb & cd & ~cc) | (ca & cc & cd & ~cb) | (cb & cc & cd & ~ca);
+                uint32_t act = vert | conc;
+                if (!act)
+                    continue;
+                const uint32_t su = cb & ~ca, sd = cd & ~cc;  // run starts of the two rows within this word
+                const uint32_t pu = up ? pre[(vy - 1) * wcH + w] : 0u, pd = dn ? pre[vy * wcH + w] : 0u;
                 while (act) {
                     const int bit = __ffs((int)act) - 1;
                     act &= act - 1;
+                    const uint32_t le = sil_le(bit);
                     const int vx = 32 * w + bit;
-                    const uint32_t code = ((ca >> bit) & 1u) | (((cb >> bit) & 1u) << 1) | (((cc >> bit) & 1u) << 2) |
-                                          (((cd >> bit) & 1u) << 3);
-                    // pixels around the corner: a = (vx-1, vy-1), b = (vx, vy-1), c = (vx-1, vy), d = (vx, vy)
-                    int px, py, qx, qy;
-                    switch (code) {
-                    case 0x3: px = vx - 1, py = vy - 1, qx = vx, qy = vy - 1; break;      // a -> b
-                    case 0xC: px = vx, py = vy, qx = vx - 1, qy = vy; break;              // d -> c
-                    case 0x5: px = vx - 1, py = vy, qx = vx - 1, qy = vy - 1; break;      // c -> a
-                    case 0xA: px = vx, py = vy - 1, qx = vx, qy = vy; break;              // b -> d
-                    case 0x7: px = vx - 1, py = vy, qx = vx, qy = vy - 1; break;          // c -> b
-                    case 0xB: px = vx - 1, py = vy - 1, qx = vx, qy = vy; break;          // a -> d
-                    case 0xD: px = vx, py = vy, qx = vx - 1, qy = vy - 1; break;          // d -> a
-                    default: px = vx, py = vy - 1, qx = vx - 1, qy = vy; break;           // 0xE: b -> c
+                    // any set pixel at the corner names the component: d, else b, else c (then a and c alone are set)
+                    uint32_t run;
+                    if ((cd >> bit) & 1u)
+                        run = pd + __popc(sd & le) - 1u;
+                    else if ((cb >> bit) & 1u)
+                        run = pu + __popc(su & le) - 1u;
+                    else
+                        run = sil_run_at(mB, pre, vy, vx - 1, wcH, wpr);
+                    const int mag = 2 * vx - 1, st = (int)((vert >> bit) & 1u);  // qx + px: 2vx - 1 across a corner pixel
+                    const int contrib = ((ca & cc) >> bit) & 1u ? st - mag : mag + st;  // 2vx - 2 up the left side, 2vx down the right
+                    const uint32_t root = fg.parent[run];
+                    if (root != acc_root) {
+                        if (acc_root != 0xFFFFFFFFu)
+                            atomicAdd(&fg.val[acc_root], acc);
+                        acc_root = root;
+                        acc = 0u;
                     }
-                    const uint32_t root = fg.parent[sil_run_at(mB, pre, py, px, wcH, wpr)];
-                    atomicAdd(&fg.val[root], (uint32_t)(px * qy - py * qx));
+                    acc += (uint32_t)contrib;
                 }
             }
+            if (acc_root != 0xFFFFFFFFu)
+                atomicAdd(&fg.val[acc_root], acc);
             __threadfence_block();
             __syncthreads();
+            SIL_TICK(18);
             // (5) the largest area; among equals the contour found last in raster order (cv2.findContours lists
             // the contours in reverse order of discovery and max() keeps the first)
             for (int r = t; r < fg.n; r += FX_BLOCK) {
@@ -1119,7 +1174,7 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_mask_kernel(SilArgs A)
             if (fg.n > 0) {
                 const uint32_t best = (uint32_t)(s_best & 0xFFFFFFFFull);
                 for (int wi = t; wi < H * wcH; wi += FX_BLOCK) {
-                    const int y = wi / wcH, w = wi - y * wcH;
+                    const int y = sil_div(wi, GH.dv), w = wi - y * wcH;
                     sil_for_segments(mB, pre, y, w, wcH, wpr, [&](uint32_t seg, uint32_t id) {
                         if (fg.parent[id] != best)
                             return;
@@ -1221,47 +1276,86 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_mask_kernel(SilArgs A)
 
         SIL_TICK(6);
         // ---- resized mask (new_h x new_w) into mB
-        const int wcS = (new_w + 31) >> 5;
-        for (int wi = t; wi < new_h * wcS; wi += FX_BLOCK) {
-            const int y = wi / wcS, w = wi - y * wcS;
-            const uint32_t sy = s_ytab[y];
-            uint32_t word = 0;
-            if (sy != 0xFFFFu) {
-                const uint32_t *r = mA + (cy0 + (int)sy) * wpr;
-                uint32_t sx[32];
-#pragma unroll
-                for (int k = 0; k < 32; k++)
-                    sx[k] = s_xtab[32 * w + k];
+        const SilGeom GS = sil_geom(new_h, new_w);
+        const int wcS = GS.wc;
+        if (cw <= new_w) {
+            // Enlarging (the usual case: a cropped view back to the working size): the source columns of an
+            // output word never step by more than one pixel, so they lie inside the 32 pixels that start at the
+            // word's first source column.  A thread keeps a word column's 32 offsets in registers and walks
+            // down a strip of rows: two mask words and two instructions per output bit, instead of two LDS
+            // reads per bit.
+            for (int it = t; it < wcS * GS.strips; it += FX_BLOCK) {
+                const int sy_ = sil_div(it, GS.dv), w = it - sy_ * wcS, y0 = sy_ * GS.rs;
+                if (y0 >= new_h)
+                    continue;
+                const int y1 = y0 + GS.rs < new_h ? y0 + GS.rs : new_h;
+                const uint32_t first = s_xtab[32 * w];  // x = 32 w < new_w: a valid entry
+                uint32_t off[32], valid = 0u;
 #pragma unroll
                 for (int k = 0; k < 32; k++) {
-                    const int x = cx0 + (int)(sx[k] == 0xFFFFu ? 0u : sx[k]);
-                    const uint32_t bit = (r[x >> 5] >> (x & 31)) & 1u;
-                    word |= (sx[k] == 0xFFFFu ? 0u : bit) << k;
+                    const uint32_t e = s_xtab[32 * w + k];
+                    off[k] = (e - first) & 31u;
+                    valid |= (e != 0xFFFFu ? 1u : 0u) << k;
+                }
+                const int x0 = cx0 + (int)first, xw = x0 >> 5, xs = x0 & 31;
+                for (int y = y0; y < y1; y++) {
+                    const uint32_t sy = s_ytab[y];
+                    uint32_t word = 0;
+                    if (sy != 0xFFFFu) {
+                        const uint32_t *r = mA + (cy0 + (int)sy) * wpr;
+                        const uint32_t lo = r[xw], hi = xw + 1 < wpr ? r[xw + 1] : 0u;
+                        const uint32_t win = xs ? (lo >> xs) | (hi << (32 - xs)) : lo;
+#pragma unroll
+                        for (int k = 0; k < 32; k++)
+                            word |= ((win >> off[k]) & 1u) << k;
+                        word &= valid;
+                    }
+                    mB[y * wpr + w] = word;
                 }
             }
-            mB[y * wpr + w] = word;
+        } else {
+            for (int wi = t; wi < new_h * wcS; wi += FX_BLOCK) {
+                const int y = sil_div(wi, GS.dv), w = wi - y * wcS;
+                const uint32_t sy = s_ytab[y];
+                uint32_t word = 0;
+                if (sy != 0xFFFFu) {
+                    const uint32_t *r = mA + (cy0 + (int)sy) * wpr;
+                    uint32_t sx[32];
+#pragma unroll
+                    for (int k = 0; k < 32; k++)
+                        sx[k] = s_xtab[32 * w + k];
+#pragma unroll
+                    for (int k = 0; k < 32; k++) {
+                        const int x = cx0 + (int)(sx[k] == 0xFFFFu ? 0u : sx[k]);
+                        const uint32_t bit = (r[x >> 5] >> (x & 31)) & 1u;
+                        word |= (sx[k] == 0xFFFFu ? 0u : bit) << k;
+                    }
+                }
+                mB[y * wpr + w] = word;
+            }
         }
         __syncthreads();
 
         SIL_TICK(7);
         // ---- opening of the resized mask (reference :246-264): 3x3 box, or cv2's 3x3 ellipse (a cross)
         if (!cv) {
-            sil_morph<false>(mB, mA, new_h, new_w, wpr);
-            sil_morph<true>(mA, mB, new_h, new_w, wpr);
+            sil_morph<false>(mB, mA, GS, wpr);
+            sil_morph<true>(mA, mB, GS, wpr);
         } else {
-            sil_morph_cv<false, false>(mB, mA, new_h, new_w, wpr);
-            sil_morph_cv<true, false>(mA, mB, new_h, new_w, wpr);
+            sil_morph_cv<false, false>(mB, mA, GS, wpr);
+            sil_morph_cv<true, false>(mA, mB, GS, wpr);
         }
 
         SIL_TICK(8);
+        SIL_TICK(9);
         // ---- connected components over row runs: 4-connected (scipy.ndimage.label) or 8-connected
         // (cv2.connectedComponentsWithStats(connectivity=8)), reference :284-311
         const int nwS = new_h * wcS;
-        SilRuns cc = sil_label(mB, new_h, wcS, wpr, cv, pre, s_scan, &s_v[SV_NRUNS], s_runs, glob_runs, A.run_cap);
+        SilRuns cc = sil_label(mB, new_h, wcS, GS.dv, wpr, cv, pre, s_scan, &s_v[SV_NRUNS], s_runs, glob_runs, A.run_cap);
         SIL_TICK(10);
         // component sizes
         for (int wi = t; wi < nwS; wi += FX_BLOCK) {
-            const int y = wi / wcS, w = wi - y * wcS;
+            const int y = sil_div(wi, GS.dv), w = wi - y * wcS;
             sil_for_segments(mB, pre, y, w, wcS, wpr, [&](uint32_t seg, uint32_t id) {
                 atomicAdd(&cc.val[cc.parent[id]], (uint32_t)__popc(seg));
             });
@@ -1285,7 +1379,7 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_mask_kernel(SilArgs A)
         if (!any_keep && cc.n > 0) {
             const uint32_t maxsz = (uint32_t)s_v[SV_MAXSZ];
             for (int wi = t; wi < nwS; wi += FX_BLOCK) {
-                const int y = wi / wcS, w = wi - y * wcS;
+                const int y = sil_div(wi, GS.dv), w = wi - y * wcS;
                 sil_for_segments(mB, pre, y, w, wcS, wpr, [&](uint32_t seg, uint32_t id) {
                     const uint32_t root = cc.parent[id];
                     if (cc.val[root] != maxsz)
@@ -1300,7 +1394,7 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_mask_kernel(SilArgs A)
         const uint32_t best_root = (uint32_t)(s_first & 0xFFFFFFFFull);
         // kept pixels into mA
         for (int wi = t; wi < nwS; wi += FX_BLOCK) {
-            const int y = wi / wcS, w = wi - y * wcS;
+            const int y = sil_div(wi, GS.dv), w = wi - y * wcS;
             uint32_t kept = 0u;
             sil_for_segments(mB, pre, y, w, wcS, wpr, [&](uint32_t seg, uint32_t id) {
                 const uint32_t root = cc.parent[id];
@@ -1318,7 +1412,7 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_mask_kernel(SilArgs A)
         if ((res & 15) == 0) {
             const int cpr = res >> 4;
             for (int ci = t; ci < res * cpr; ci += FX_BLOCK) {
-                const int Y = ci / cpr, X0 = (ci - Y * cpr) * 16;
+                const int Y = sil_div(ci, dvP), X0 = (ci - Y * cpr) * 16;
                 const int y = Y - py0;
                 uint32_t o[4] = {0u, 0u, 0u, 0u};
                 const int x = X0 - px0;  // mask column of the chunk's first pixel
@@ -1346,11 +1440,15 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_mask_kernel(SilArgs A)
         }
         SIL_TICK(13);
 #ifdef SIL_TIMING
-        if (t == 0 && blockIdx.x == 0 && b == 0) {
+        if (t == 0 && blockIdx.x == 0 && b == SIL_TICK_IMG) {
             printf("sil ticks:");
             for (int i = 1; i <= 13; i++)
                 printf(" %d:%llu", i, s_tick[i] - s_tick[i - 1]);
             printf(" total %llu\n", s_tick[13] - s_tick[0]);
+            if (cv)
+                printf("  contour stage: complement %llu bg-label %llu holes %llu fg-label %llu corners %llu best+box %llu\n",
+                       s_tick[14] - s_tick[3], s_tick[15] - s_tick[14], s_tick[16] - s_tick[15], s_tick[17] - s_tick[16],
+                       s_tick[18] - s_tick[17], s_tick[4] - s_tick[18]);
         }
 #endif
         if (A.info && t == 0) {
