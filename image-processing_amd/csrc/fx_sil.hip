@@ -509,28 +509,42 @@ __device__ void sil_morph_cv(const uint32_t *s, uint32_t *d, const SilGeom &G, i
         if (y0 >= rows)
             continue;
         const int y1 = y0 + rs < rows ? y0 + rs : rows;
-        auto word = [&](int yy, int ww) -> uint32_t {
-            if (yy < 0 || yy >= rows || ww < 0 || ww >= wc)
-                return fill;
-            uint32_t m = s[yy * wpr + ww];
-            if (!DILATE && ww == wc - 1)
-                m |= ~lastmask;
-            return m;
-        };
-        auto centre = [&](int yy) -> uint32_t { return word(yy, w); };
-        auto wide = [&](int yy) -> uint32_t {
-            const uint32_t m = word(yy, w), p = word(yy, w - 1), n = word(yy, w + 1);
+        // what the thread's word column decides once: which neighbour words exist, and for an erosion the
+        // bits beyond `cols` of the last word (outside the image: foreground)
+        const bool has_p = w > 0, has_n = w + 1 < wc;
+        const uint32_t fix_m = (!DILATE && w == wc - 1) ? ~lastmask : 0u;
+        const uint32_t fix_n = (!DILATE && w + 1 == wc - 1) ? ~lastmask : 0u;
+        const uint32_t *col = s + w;
+        // the word of row yy (c) and its combination over the element's widest rows (wd)
+        auto load = [&](int yy, uint32_t &c, uint32_t &wd) {
+            uint32_t m = fill, p = fill, n = fill;
+            if ((unsigned)yy < (unsigned)rows) {
+                const uint32_t *r = col + yy * wpr;
+                m = r[0] | fix_m;
+                if (has_p)
+                    p = r[-1];
+                if (has_n)
+                    n = r[1] | fix_n;
+            }
             const uint32_t l1 = (m << 1) | (p >> 31), r1 = (m >> 1) | (n << 31);
-            if (!FIVE)
-                return DILATE ? (m | l1 | r1) : (m & l1 & r1);
-            const uint32_t l2 = (m << 2) | (p >> 30), r2 = (m >> 2) | (n << 30);
-            return DILATE ? (m | l1 | r1 | l2 | r2) : (m & l1 & r1 & l2 & r2);
+            c = m;
+            if (!FIVE) {
+                wd = DILATE ? (m | l1 | r1) : (m & l1 & r1);
+            } else {
+                const uint32_t l2 = (m << 2) | (p >> 30), r2 = (m >> 2) | (n << 30);
+                wd = DILATE ? (m | l1 | r1 | l2 | r2) : (m & l1 & r1 & l2 & r2);
+            }
         };
+        uint32_t unused;
         if (FIVE) {
-            uint32_t cm2 = centre(y0 - 2), wm1 = wide(y0 - 1), w0 = wide(y0), wp1 = wide(y0 + 1);
-            uint32_t cm1 = centre(y0 - 1), c0 = centre(y0), cp1 = centre(y0 + 1);  // centre words of rows that later are row -2
+            uint32_t cm2, cm1, c0, cp1, wm1, w0, wp1;
+            load(y0 - 2, cm2, unused);
+            load(y0 - 1, cm1, wm1);
+            load(y0, c0, w0);
+            load(y0 + 1, cp1, wp1);
             for (int y = y0; y < y1; y++) {
-                const uint32_t cp2 = centre(y + 2);
+                uint32_t cp2, wp2;
+                load(y + 2, cp2, wp2);
                 uint32_t acc = DILATE ? (cm2 | wm1 | w0 | wp1 | cp2) : (cm2 & wm1 & w0 & wp1 & cp2);
                 if (w == wc - 1)
                     acc &= lastmask;
@@ -541,19 +555,22 @@ __device__ void sil_morph_cv(const uint32_t *s, uint32_t *d, const SilGeom &G, i
                 cp1 = cp2;
                 wm1 = w0;
                 w0 = wp1;
-                wp1 = wide(y + 2);
+                wp1 = wp2;
             }
         } else {
-            uint32_t cm1 = centre(y0 - 1), w0 = wide(y0), c0 = centre(y0);
+            uint32_t cm1, c0, w0;
+            load(y0 - 1, cm1, unused);
+            load(y0, c0, w0);
             for (int y = y0; y < y1; y++) {
-                const uint32_t cp1 = centre(y + 1);
+                uint32_t cp1, wp1;
+                load(y + 1, cp1, wp1);
                 uint32_t acc = DILATE ? (cm1 | w0 | cp1) : (cm1 & w0 & cp1);
                 if (w == wc - 1)
                     acc &= lastmask;
                 d[y * wpr + w] = acc;
                 cm1 = c0;
                 c0 = cp1;
-                w0 = wide(y + 1);
+                w0 = wp1;
             }
         }
     }
@@ -848,6 +865,8 @@ __device__ __forceinline__ void sil_box_reduce(int mnx, int mny, int mxx, int mx
     }
 }
 
+// CV: the OpenCV branch of the reference (A.mode == FX_SIL_OPENCV), else its PIL / scipy branch.
+template <bool CV>
 __global__ __launch_bounds__(FX_BLOCK, 4) void sil_mask_kernel(SilArgs A)
 {
     extern __shared__ __align__(16) uint8_t sil_smem[];
@@ -885,7 +904,7 @@ __global__ __launch_bounds__(FX_BLOCK, 4) void sil_mask_kernel(SilArgs A)
         }
         __syncthreads();
         SIL_TICK(0);
-        const bool cv = A.mode == FX_SIL_OPENCV;
+        constexpr bool cv = CV;
         uint32_t *glob_runs = A.runs + (int64_t)blockIdx.x * 2 * A.run_cap;
         if (cv) {
             if (t == 0)
@@ -1511,7 +1530,10 @@ extern "C" int fx_silhouette_batch_u8(const uint8_t *d_img, int64_t B, int H, in
         int dev = 0, cus = 0, per_cu = 0;
         if (hipGetDevice(&dev) == hipSuccess &&
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sil_mask_kernel, FX_BLOCK, mask_lds) == hipSuccess &&
+            (mode == FX_SIL_OPENCV
+                 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sil_mask_kernel<true>, FX_BLOCK, mask_lds)
+                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sil_mask_kernel<false>, FX_BLOCK, mask_lds)) ==
+                hipSuccess &&
             cus > 0 && per_cu > 0)
             grid = cus * per_cu;
         grid = grid > 4096 ? 4096 : grid;
@@ -1578,8 +1600,9 @@ extern "C" int fx_silhouette_batch_u8(const uint8_t *d_img, int64_t B, int H, in
                                          (int)otsu_lds));
     }
     if (mask_lds > 48 * 1024)  // beyond the default limit of dynamic LDS; set per call: the current device may differ
-        FX_HIP_CHECK(hipFuncSetAttribute((const void *)sil_mask_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)mask_lds));
+        FX_HIP_CHECK(hipFuncSetAttribute(mode == FX_SIL_OPENCV ? (const void *)sil_mask_kernel<true>
+                                                               : (const void *)sil_mask_kernel<false>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)mask_lds));
 
     for (int64_t b0 = 0; b0 < B; b0 += chunk) {
         const int64_t nb = B - b0 < chunk ? B - b0 : chunk;
@@ -1605,7 +1628,10 @@ extern "C" int fx_silhouette_batch_u8(const uint8_t *d_img, int64_t B, int H, in
         const int g = (int)(nb < grid ? nb : grid);  // persistent blocks: as many as are resident at once
         {
             FxProfileScope prof(stream);  // the longer of the two kernels; the last chunk's launch is what stays
-            hipLaunchKernelGGL(sil_mask_kernel, dim3(g), dim3(FX_BLOCK), mask_lds, stream, A);
+            if (mode == FX_SIL_OPENCV)
+                hipLaunchKernelGGL(sil_mask_kernel<true>, dim3(g), dim3(FX_BLOCK), mask_lds, stream, A);
+            else
+                hipLaunchKernelGGL(sil_mask_kernel<false>, dim3(g), dim3(FX_BLOCK), mask_lds, stream, A);
         }
         FX_HIP_CHECK(hipGetLastError());
     }
