@@ -124,6 +124,16 @@ __device__ __forceinline__ float fx_wave_max_f32_dpp(float v)
     v = fmaxf(v, fx_dpp_f32<0x143, 0xc>(v));  // row_bcast:31 into rows 2 and 3
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+__device__ __forceinline__ float fx_wave_min_f32_dpp(float v)
+{
+    v = fminf(v, fx_dpp_f32<0xB1, 0xf>(v));
+    v = fminf(v, fx_dpp_f32<0x4E, 0xf>(v));
+    v = fminf(v, fx_dpp_f32<0x141, 0xf>(v));
+    v = fminf(v, fx_dpp_f32<0x140, 0xf>(v));
+    v = fminf(v, fx_dpp_f32<0x142, 0xa>(v));
+    v = fminf(v, fx_dpp_f32<0x143, 0xc>(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 __device__ __forceinline__ double fx_wave_max_f64_dpp(double v)
 {
     v = fmax(v, fx_dpp_f64<0xB1, 0xf>(v));

@@ -48,7 +48,7 @@ def test_center_and_scale_batch_against_oracle(gpu, oracle):
         np.testing.assert_array_equal(got[k][1], want[1], err_msg=f"cloud {k}")
 
 
-@pytest.mark.parametrize("M,n", [(20, 8), (1025, 1024), (3000, 1024), (16384, 512), (16385, 300), (60000, 1024)])
+@pytest.mark.parametrize("M,n", [(20, 8), (1025, 1024), (3000, 1024), (16384, 512), (16385, 300), (60000, 1024), (100000, 1024)])
 def test_fps_against_oracle(gpu, oracle, M, n):
     prep = pkg("prepare_all")
     rng = np.random.default_rng(M + n)
@@ -77,6 +77,48 @@ def test_fps_ties_and_host_branches(gpu, oracle):
     assert prep.farthest_point_sampling(np.zeros((0, 3), np.float32), 5).size == 0
     with pytest.raises(ValueError, match="float32"):
         prep.farthest_point_sampling(np.random.default_rng(0).normal(size=(100, 3)), 10)
+
+
+def test_fps_large_clouds_structured(gpu, oracle):
+    """Clouds beyond the register kernels (cell-sorted kernel): lattices whose distances tie exactly or in the
+    last bits, duplicates, clusters far apart, a line, more samples than distinct points."""
+    prep = pkg("prepare_all")
+    rng = np.random.default_rng(77)
+    g = np.stack(np.meshgrid(np.arange(32.0), np.arange(32.0), np.arange(20.0), indexing="ij"), -1).reshape(-1, 3)
+    lattice = (g * np.float32(0.1)).astype(np.float32)                      # 20480 points, inexact spacing
+    twice = np.concatenate([g, g[::-1]], axis=0).astype(np.float32)        # every point twice
+    clusters = np.concatenate([rng.normal(size=(9000, 3)) * 0.01 + c for c in ((0, 0, 0), (5, 0, 0), (0, 7, 1))])
+    line = np.zeros((30000, 3)); line[:, 0] = rng.permutation(30000) * 0.001
+    few = np.tile(rng.normal(size=(50, 3)), (400, 1))                      # 50 distinct points, 20000 rows
+    one = np.tile(np.array([[0.5, -1.0, 2.0]]), (17000, 1))
+    cases = [(lattice, 700, None), (twice, 300, 5), (clusters.astype(np.float32), 1024, 1), (line.astype(np.float32), 512, 2),
+             (few.astype(np.float32), 120, 3), (one.astype(np.float32), 7, 4)]
+    for k, (pts, n, seed) in enumerate(cases):
+        r1 = np.random.RandomState(seed) if seed is not None else None
+        r2 = np.random.RandomState(seed) if seed is not None else None
+        np.testing.assert_array_equal(prep.farthest_point_sampling(pts, n, r1),
+                                      oracle.farthest_point_sampling(pts, n, r2), err_msg=f"case {k}")
+
+
+def test_fps_large_batch_mixed_sizes(gpu, oracle):
+    """One call with clouds of every size class, 100 000 and 300 000 points among them (groups of 256 points)."""
+    eng = pkg("engine")
+    rng = np.random.default_rng(31)
+    sizes = [100000, 900, 16385, 300000, 5000, 40000]
+    clouds = [oracle.center_and_scale(cloud(rng, M).astype(np.float64))[0] for M in sizes]
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    start = np.array([rng.integers(0, M) for M in sizes], dtype=np.int64)
+    pts = torch.from_numpy(np.concatenate(clouds)).to(gpu)
+    n = 256
+    got = eng.fps(pts, off, n, start)
+    idx = got["idx"].cpu().numpy()
+    for k, c in enumerate(clouds):
+        class Fixed:                       # the oracle draws its start index from the caller's generator
+            def randint(self, lo, hi, k=k):
+                return int(start[k])
+        want = oracle.farthest_point_sampling(c, n, Fixed())
+        np.testing.assert_array_equal(idx[k], want, err_msg=f"cloud {k}")
+        np.testing.assert_array_equal(got["sampled"][k].cpu().numpy(), c[want])
 
 
 def test_normalize_and_sample_pipeline(gpu, oracle):

@@ -107,7 +107,7 @@ if __name__ == "__main__":
             ms, gbps = time_hu(B,H,W,c)
             print(f"hu B={B} {H}x{W} contour={c} dbg={os.environ.get('FX_DBG','0')}: {ms:.3f} ms  {gbps:.0f} GB/s", flush=True)
     elif what == "fps":
-        for (B,M,n) in [(4000,2048,1024),(2000,8192,1024),(512,16384,1024),(64,100000,1024)]:
+        for (B,M,n) in [(4000,2048,1024),(2000,8192,1024),(512,16384,1024),(64,100000,1024),(64,100000,2),(256,100000,1024),(1024,20000,1024),(8,4000000,1024)]:
             cs, fp = time_fps(B,M,n)
             print(f"fps B={B} M={M} n={n}: center_scale {cs:.3f} ms ({B*M*12/cs/1e6:.0f} GB/s)  fps {fp:.3f} ms  {B/fp*1e3:.0f} clouds/s  {B*M*n/fp/1e6:.1f} G point-updates/s", flush=True)
     elif what == "bin":
