@@ -270,44 +270,49 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_blur_cv_kernel(SilArgs A)
         const int i = it / cpr, c = it - i * cpr;
         const uint8_t *row = src + (int64_t)sil_refl101(r0 - SIL_CV_HALO + i, H) * A.pitch;
         const int x0 = c * 16;
-        uint32_t v[20];
+        uint4 *dst = (uint4 *)(tile + (size_t)i * Wp + x0);
         if (ALIGNED) {   // W is a multiple of 16 (so at least 16) and rows are 16-byte aligned
+            // Pairs of neighbouring pixels as two 16-bit fields of a word, P[j] = (pixel j - 2, pixel j - 1)
+            // counted from the chunk's first pixel: one byte permute each.  A sum of the five taps is at most
+            // 255 * 16, so plain 32-bit arithmetic on such words never carries from one field into the other
+            // and two output pixels cost four instructions.
             const uint4 m = *(const uint4 *)(row + x0);
-            const uint32_t mw[4] = {m.x, m.y, m.z, m.w};
+            // left word: bytes 2, 3 = pixels x0 - 2, x0 - 1 (reflected at the row's start: pixels 2, 1)
+            const uint32_t l = x0 > 0 ? *(const uint32_t *)(row + x0 - 4) : __builtin_amdgcn_perm(0u, m.x, 0x01020c0cu);
+            // right word: bytes 0, 1 = pixels x0 + 16, x0 + 17 (reflected at the row's end: pixels 14, 13)
+            const uint32_t r = x0 + 16 < W ? *(const uint32_t *)(row + x0 + 16) : __builtin_amdgcn_perm(0u, m.w, 0x0c0c0102u);
+            const uint32_t wd[6] = {l, m.x, m.y, m.z, m.w, r};
+            uint32_t P[19];
 #pragma unroll
-            for (int k = 0; k < 16; k++)
-                v[2 + k] = (mw[k >> 2] >> (8 * (k & 3))) & 255u;
-            if (x0 > 0) {
-                const uint32_t l = *(const uint32_t *)(row + x0 - 4);
-                v[0] = (l >> 16) & 255u;
-                v[1] = l >> 24;
-            } else {
-                v[0] = v[4];   // x = -2 -> 2
-                v[1] = v[3];   // x = -1 -> 1
+            for (int j = 0; j < 19; j++) {
+                // first pixel of the pair is byte (j + 2) & 3 of word (j + 2) >> 2
+                const int w0 = (j + 2) >> 2, b0 = (j + 2) & 3;
+                P[j] = b0 == 0   ? __builtin_amdgcn_perm(0u, wd[w0], 0x0c010c00u)
+                       : b0 == 1 ? __builtin_amdgcn_perm(0u, wd[w0], 0x0c020c01u)
+                       : b0 == 2 ? __builtin_amdgcn_perm(0u, wd[w0], 0x0c030c02u)
+                                 : __builtin_amdgcn_perm(wd[w0 + 1], wd[w0], 0x0c040c03u);
             }
-            if (x0 + 16 < W) {
-                const uint32_t r = *(const uint32_t *)(row + x0 + 16);
-                v[18] = r & 255u;
-                v[19] = (r >> 8) & 255u;
-            } else {
-                v[18] = v[16];  // x = W -> W - 2
-                v[19] = v[15];  // x = W + 1 -> W - 3
-            }
+            uint32_t o[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                o[k] = P[2 * k] + P[2 * k + 4] + 4u * (P[2 * k + 1] + P[2 * k + 3]) + 6u * P[2 * k + 2];
+            dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+            dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
         } else {
+            uint32_t v[20];
 #pragma unroll
             for (int k = 0; k < 20; k++)
                 v[k] = row[sil_refl101(x0 - SIL_CV_HALO + k, W)];
-        }
-        uint32_t o[8];
+            uint32_t o[8];
 #pragma unroll
-        for (int k = 0; k < 16; k += 2) {
-            const uint32_t lo = v[k] + v[k + 4] + 4u * (v[k + 1] + v[k + 3]) + 6u * v[k + 2];
-            const uint32_t hi = v[k + 1] + v[k + 5] + 4u * (v[k + 2] + v[k + 4]) + 6u * v[k + 3];
-            o[k >> 1] = lo | (hi << 16);
+            for (int k = 0; k < 16; k += 2) {
+                const uint32_t lo = v[k] + v[k + 4] + 4u * (v[k + 1] + v[k + 3]) + 6u * v[k + 2];
+                const uint32_t hi = v[k + 1] + v[k + 5] + 4u * (v[k + 2] + v[k + 4]) + 6u * v[k + 3];
+                o[k >> 1] = lo | (hi << 16);
+            }
+            dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+            dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
         }
-        uint4 *dst = (uint4 *)(tile + (size_t)i * Wp + x0);
-        dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
-        dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
     }
     __syncthreads();
 
@@ -842,7 +847,7 @@ __device__ __forceinline__ void sil_for_segments(const uint32_t *m, const uint32
 
 enum {
     SV_COUNT = 0, SV_THRESH, SV_INV, SV_MINX, SV_MINY, SV_MAXX, SV_MAXY, SV_CX0, SV_CY0, SV_CW, SV_CH, SV_NW,
-    SV_NH, SV_NRUNS, SV_ANYKEEP, SV_NEAR, SV_MAXSZ, SV_N
+    SV_NH, SV_NRUNS, SV_ANYKEEP, SV_NEAR, SV_MAXSZ, SV_HOLES4, SV_N
 };
 
 // Block-wide bounding box: per-thread extremes into s_v[SV_MINX .. SV_MAXY].
@@ -867,7 +872,7 @@ __device__ __forceinline__ void sil_box_reduce(int mnx, int mny, int mxx, int mx
 
 // CV: the OpenCV branch of the reference (A.mode == FX_SIL_OPENCV), else its PIL / scipy branch.
 template <bool CV>
-__global__ __launch_bounds__(FX_BLOCK, 4) void sil_mask_kernel(SilArgs A)
+__global__ __launch_bounds__(FX_BLOCK, 5) void sil_mask_kernel(SilArgs A)
 {
     extern __shared__ __align__(16) uint8_t sil_smem[];
     __shared__ double s_between[FX_WAVES_PER_BLOCK];
@@ -1084,14 +1089,44 @@ __global__ __launch_bounds__(FX_BLOCK, 4) void sil_mask_kernel(SilArgs A)
 
             SIL_TICK(3);
             // ---- box of the external contour with the largest contourArea (reference :198-221).
+            // The external contours are the 8-connected components of the mask with its holes filled.  Most
+            // masks have no hole, and then the mask's own components are those: label the mask as it is, count
+            // its components C, and take the Euler number E (components minus holes) from the 2 x 2 windows
+            // around the corners of the pixel grid: 4 E = #(one pixel set) - #(three set) - 2 #(a diagonal pair).
+            SIL_TICK(14);
+            SilRuns fg = sil_label(mA, H, wcH, GH.dv, wpr, true, pre, s_scan, &s_v[SV_NRUNS], s_runs, glob_runs, A.run_cap);
+            const int wcV = (W + 32) >> 5;  // corners x = 0 .. W
+            {
+                int e4 = 0;
+                for (int r = t; r < fg.n; r += FX_BLOCK)
+                    e4 -= fg.parent[r] == (uint32_t)r ? 4 : 0;
+                for (int vi = t; vi < (H + 1) * wcV; vi += FX_BLOCK) {
+                    const int vy = sil_div(vi, dvV), w = vi - vy * wcV;
+                    const uint32_t *ru = mA + (vy - 1) * wpr, *rd = mA + vy * wpr;
+                    const uint32_t up = vy > 0 && w < wcH ? ru[w] : 0u, upp = vy > 0 && w > 0 ? ru[w - 1] : 0u;
+                    const uint32_t dn = vy < H && w < wcH ? rd[w] : 0u, dnp = vy < H && w > 0 ? rd[w - 1] : 0u;
+                    const uint32_t ca = (up << 1) | (upp >> 31), cb = up, cc = (dn << 1) | (dnp >> 31), cd = dn;
+                    const uint32_t odd = ca ^ cb ^ cc ^ cd;
+                    const uint32_t three = odd & ((ca & cb) | (cc & cd));
+                    const uint32_t diag = (ca & cd & ~(cb | cc)) | (cb & cc & ~(ca | cd));
+                    e4 += __popc(odd & ~three) - __popc(three) - 2 * __popc(diag);
+                }
+#pragma unroll
+                for (int o = FX_WAVE / 2; o > 0; o >>= 1)
+                    e4 += __shfl_xor(e4, o, FX_WAVE);
+                if (fx_lane() == 0 && e4)
+                    atomicAdd(&s_v[SV_HOLES4], e4);   // 4 (E - C) = -4 holes
+            }
+            __syncthreads();
+            SIL_TICK(15);
+            const uint32_t *mF = mA;   // the mask whose components are the external contours
+            if (s_v[SV_HOLES4] != 0) {
             // (1) background runs, 4-connected; those that reach the image frame are the outside
             for (int wi = t; wi < H * wcH; wi += FX_BLOCK) {
                 const int y = sil_div(wi, GH.dv), w = wi - y * wcH;
                 mB[y * wpr + w] = ~mA[y * wpr + w] & (w == wcH - 1 ? lastH : ~0u);
             }
-            SIL_TICK(14);
             SilRuns bg = sil_label(mB, H, wcH, GH.dv, wpr, false, pre, s_scan, &s_v[SV_NRUNS], s_runs, glob_runs, A.run_cap);
-            SIL_TICK(15);
             for (int wi = t; wi < H * wcH; wi += FX_BLOCK) {
                 const int y = sil_div(wi, GH.dv), w = wi - y * wcH;
                 sil_for_segments(mB, pre, y, w, wcH, wpr, [&](uint32_t seg, uint32_t id) {
@@ -1126,7 +1161,9 @@ __global__ __launch_bounds__(FX_BLOCK, 4) void sil_mask_kernel(SilArgs A)
             }
             // (3) 8-connected components of the filled mask = the external contours
             SIL_TICK(16);
-            SilRuns fg = sil_label(mB, H, wcH, GH.dv, wpr, true, pre, s_scan, &s_v[SV_NRUNS], s_runs, glob_runs, A.run_cap);
+            fg = sil_label(mB, H, wcH, GH.dv, wpr, true, pre, s_scan, &s_v[SV_NRUNS], s_runs, glob_runs, A.run_cap);
+            mF = mB;
+            }
             // (4) twice the signed area inside each outer border, as a sum over the corners of the pixel grid:
             // the border follower steps between the two foreground pixels of a straight corner and cuts across
             // the background pixel of a concave corner; saddle corners give two opposite steps that cancel.
@@ -1134,11 +1171,10 @@ __global__ __launch_bounds__(FX_BLOCK, 4) void sil_mask_kernel(SilArgs A)
             // shoelace sum and to which steps along a row contribute nothing.  A step goes up (qy = py - 1)
             // exactly when both pixels left of the corner are set, and down otherwise.
             SIL_TICK(17);
-            const int wcV = (W + 32) >> 5;  // corners x = 0 .. W
             uint32_t acc_root = 0xFFFFFFFFu, acc = 0u;  // a thread's corners mostly lie on one border
             for (int vi = t; vi < (H + 1) * wcV; vi += FX_BLOCK) {
                 const int vy = sil_div(vi, dvV), w = vi - vy * wcV;
-                const uint32_t *ru = mB + (vy - 1) * wpr, *rd = mB + vy * wpr;
+                const uint32_t *ru = mF + (vy - 1) * wpr, *rd = mF + vy * wpr;
                 const uint32_t up = vy > 0 && w < wcH ? ru[w] : 0u, upp = vy > 0 && w > 0 ? ru[w - 1] : 0u;
                 const uint32_t dn = vy < H && w < wcH ? rd[w] : 0u, dnp = vy < H && w > 0 ? rd[w - 1] : 0u;
                 // pixels around the corner (vx, vy): a = (vx-1, vy-1), b = (vx, vy-1), c = (vx-1, vy), d = (vx, vy)
@@ -1162,7 +1198,7 @@ __global__ __launch_bounds__(FX_BLOCK, 4) void sil_mask_kernel(SilArgs A)
                     else if ((cb >> bit) & 1u)
                         run = pu + __popc(su & le) - 1u;
                     else
-                        run = sil_run_at(mB, pre, vy, vx - 1, wcH, wpr);
+                        run = sil_run_at(mF, pre, vy, vx - 1, wcH, wpr);
                     const int mag = 2 * vx - 1, st = (int)((vert >> bit) & 1u);  // qx + px: 2vx - 1 across a corner pixel
                     const int contrib = ((ca & cc) >> bit) & 1u ? st - mag : mag + st;  // 2vx - 2 up the left side, 2vx down the right
                     const uint32_t root = fg.parent[run];
@@ -1194,7 +1230,7 @@ __global__ __launch_bounds__(FX_BLOCK, 4) void sil_mask_kernel(SilArgs A)
                 const uint32_t best = (uint32_t)(s_best & 0xFFFFFFFFull);
                 for (int wi = t; wi < H * wcH; wi += FX_BLOCK) {
                     const int y = sil_div(wi, GH.dv), w = wi - y * wcH;
-                    sil_for_segments(mB, pre, y, w, wcH, wpr, [&](uint32_t seg, uint32_t id) {
+                    sil_for_segments(mF, pre, y, w, wcH, wpr, [&](uint32_t seg, uint32_t id) {
                         if (fg.parent[id] != best)
                             return;
                         const int lo = 32 * w + __ffs((int)seg) - 1, hi = 32 * w + 31 - __clz((int)seg);
@@ -1465,9 +1501,8 @@ __global__ __launch_bounds__(FX_BLOCK, 4) void sil_mask_kernel(SilArgs A)
                 printf(" %d:%llu", i, s_tick[i] - s_tick[i - 1]);
             printf(" total %llu\n", s_tick[13] - s_tick[0]);
             if (cv)
-                printf("  contour stage: complement %llu bg-label %llu holes %llu fg-label %llu corners %llu best+box %llu\n",
-                       s_tick[14] - s_tick[3], s_tick[15] - s_tick[14], s_tick[16] - s_tick[15], s_tick[17] - s_tick[16],
-                       s_tick[18] - s_tick[17], s_tick[4] - s_tick[18]);
+                printf("  contour stage: label + Euler %llu, holes path %llu, corners %llu best+box %llu\n",
+                       s_tick[15] - s_tick[14], s_tick[17] - s_tick[15], s_tick[18] - s_tick[17], s_tick[4] - s_tick[18]);
         }
 #endif
         if (A.info && t == 0) {
