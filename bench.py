@@ -26,8 +26,9 @@ One step = one pass of the hot path over the batch that is resident in HBM:
   f1            20 000 gray 224x224 views per GPU (dark synthetic shapes on a
                 light background + noise): silhouette preprocessing + Hu, the
                 stage in front of the headline path.
-  p1            2 000 sampled clouds per GPU -> 12 rendered views -> preprocessing
-                -> Hu -> per-sample mean/std.
+  p1            2 000 sampled clouds per GPU -> 12 rendered views -> cropped, cleaned
+                silhouettes -> Hu -> per-sample mean/std (the flags of the
+                reference's production run: --preprocess_crop --use_silhouette).
 
 Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events
 that libfx records on the launch stream around its own kernel; `cpu_baseline`
@@ -70,7 +71,7 @@ WORKLOADS = {
                     "resize, component filter) + Hu"),
     "p1": dict(kind="views+hu", per_gpu=2_000, N=1024, bytes_per_unit=1024 * 3 * 4, scaling="weak",
                desc="2k sampled clouds of 1024x3 f32 per GPU; 12 rendered 224x224 views each (the reference's matplotlib "
-                    "renderer) -> preprocessing -> Hu -> per-sample mean/std, all in HBM"),
+                    "renderer) -> cropped silhouettes (--preprocess_crop --use_silhouette) -> Hu -> per-sample mean/std, all in HBM"),
 }
 
 
@@ -215,8 +216,8 @@ def verify(kind: str, state: dict, feats) -> dict:
             r = []
             for pose in cpu_ref.compute_camera_poses(12, mins, maxs, cen):
                 view = cpu_ref.render_view(p64, pose, 224, stamp)
-                pre, _ = cpu_ref.preprocess_image_cv(view, 224, 0.05, "white", False)
-                r.append(c.hu_batch(pre[None])["hulog7"][0])
+                _, mask = cpu_ref.preprocess_image_cv(view, 224, 0.05, "white", True)
+                r.append(c.hu_batch(mask[None])["hulog7"][0])
             r = np.stack(r).astype(np.float32)
             want = np.concatenate([r.mean(axis=0), r.std(axis=0)])
             ok &= bool(np.allclose(got[k], want, rtol=1e-5, atol=1e-6))
@@ -354,7 +355,7 @@ def main(argv=None):
         elif kind == "hu":
             feats = eng.hu_batch(data, thresh=127, on_value=255)["hulog7"]
         elif kind == "views+hu":
-            feats = hu2d.hu_from_clouds_device(flat, cloud_off, 12, 224)
+            feats = hu2d.hu_from_clouds_device(flat, cloud_off, 12, 224, preprocess_crop=True, use_silhouette=True)
             first_ms.append(0.0)
         elif kind == "sil+hu":
             masks = eng.silhouette_batch(data, 224, 0.05, True)["mask"]

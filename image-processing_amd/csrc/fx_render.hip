@@ -77,6 +77,7 @@ __global__ __launch_bounds__(RENDER_THREADS) void render_views_kernel(RenderArgs
     extern __shared__ __align__(16) unsigned char lds_raw[];
     __shared__ double s_red[RENDER_WAVES];
     __shared__ uint32_t s_snap[RENDER_CHUNK];
+    __shared__ uint32_t s_list[RENDER_WAVES][FX_WAVE];   // per wave: its points of the current batch
     uint8_t *canvas = lds_raw;
     const int t = threadIdx.x;
     const int64_t bv = blockIdx.x;
@@ -130,15 +131,31 @@ __global__ __launch_bounds__(RENDER_THREADS) void render_views_kernel(RenderArgs
     // cells that fall into its stripes, a lane per cell.  A pixel belongs to one
     // wave, and the LDS operations of a wave complete in order, so the
     // read-modify-write sequences on a pixel keep the point order without any
-    // barrier.
-    const int K = A.K, half = K / 2;
+    // barrier.  Markers that share no pixel commute, so a wave takes as many
+    // consecutive points of its own as its lanes hold stamps (seven 3 x 3 stamps)
+    // in one step whenever none of them overlaps an earlier one of the step, and
+    // one after the other otherwise.
+    const int K = A.K, half = K / 2, KK = K * K;
     const int lane = fx_lane(), wave = fx_wave();
-    const int cell_dy = lane / K - half, cell_dx = lane % K - half;
-    const uint32_t alpha = lane < K * K ? A.stamp[lane] : 0u;
+    const int G = FX_WAVE / KK;                      // stamps per step
+    const int grp = lane / KK, cell = lane - grp * KK;
+    const bool lane_used = grp < G;
+    const int cell_dy = cell / K - half, cell_dx = cell % K - half;
+    const uint32_t alpha = lane_used ? A.stamp[cell] : 0u;
     const uint32_t den = ((alpha + 255u) << 8) - alpha * 255u;
     const float inv_den = 1.0f / (float)den;
     const uint32_t marker = (uint32_t)A.marker;
     auto owner = [](int row) -> int { return (row >> 3) & (RENDER_WAVES - 1); };  // of rows >= -1024
+    uint32_t *my_list = s_list[wave];
+    auto stamp_cell = [&](uint32_t rc) {
+        const int row = (int)(rc >> 16) - 1024 + cell_dy;
+        const int col = (int)(rc & 0xFFFFu) - 1024 + cell_dx;
+        if (alpha != 0u && row >= 0 && row < res && owner(row) == wave && col >= 0 && col < res) {
+            const int at = row * res + col;
+            const uint32_t p = canvas[at];
+            canvas[at] = (uint8_t)(alpha == 255u ? marker : agg_blend(p, marker, alpha, den, inv_den));
+        }
+    };
 
     for (int64_t c0 = 0; c0 < n; c0 += RENDER_CHUNK) {
         const int m = (int)(n - c0 < RENDER_CHUNK ? n - c0 : RENDER_CHUNK);
@@ -159,17 +176,35 @@ __global__ __launch_bounds__(RENDER_THREADS) void render_views_kernel(RenderArgs
             const uint32_t mine = i < m ? s_snap[i] : 0u;
             const int my_row = (int)(mine >> 16) - 1024;
             // a stamp of at most 7 rows touches one or two stripes
-            unsigned long long todo = __ballot(i < m && (owner(my_row - half + 1024) == wave || owner(my_row + half + 1024) == wave));
-            while (todo) {
-                const int j = __ffsll((long long)todo) - 1;
-                todo &= todo - 1;
-                const uint32_t rc = (uint32_t)__builtin_amdgcn_readlane((int)mine, j);
-                const int row = (int)(rc >> 16) - 1024 + cell_dy;
-                const int col = (int)(rc & 0xFFFFu) - 1024 + cell_dx;
-                if (alpha != 0u && row >= 0 && row < res && owner(row) == wave && col >= 0 && col < res) {
-                    const int at = row * res + col;
-                    const uint32_t p = canvas[at];
-                    canvas[at] = (uint8_t)(alpha == 255u ? marker : agg_blend(p, marker, alpha, den, inv_den));
+            const bool take = i < m && (owner(my_row - half + 1024) == wave || owner(my_row + half + 1024) == wave);
+            unsigned long long todo = __ballot(take);
+            if (G < 2) {
+                while (todo) {
+                    const int j = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    stamp_cell((uint32_t)__builtin_amdgcn_readlane((int)mine, j));
+                }
+                continue;
+            }
+            // the wave's points of this batch, in order
+            const int cnt = __popcll(todo);
+            if (take)
+                my_list[__builtin_amdgcn_mbcnt_hi((unsigned int)(todo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)todo, 0u))] = mine;
+            for (int g0 = 0; g0 < cnt; g0 += G) {
+                const bool live = lane_used && g0 + grp < cnt;
+                const uint32_t rc = live ? my_list[g0 + grp] : 0u;
+                // lane (grp, cell) compares stamp grp with the earlier stamp number `cell` of the step
+                const uint32_t other = (uint32_t)__shfl((int)rc, cell * KK, FX_WAVE);
+                const int dr = (int)(rc >> 16) - (int)(other >> 16), dc = (int)(rc & 0xFFFFu) - (int)(other & 0xFFFFu);
+                const bool clash = live && cell < grp && (unsigned)(dr + K - 1) < (unsigned)(2 * K - 1) &&
+                                   (unsigned)(dc + K - 1) < (unsigned)(2 * K - 1);
+                if (!__ballot(clash)) {
+                    if (live)
+                        stamp_cell(rc);
+                } else {
+                    for (int e = 0; e < G && g0 + e < cnt; e++)
+                        if (live && grp == e)
+                            stamp_cell(rc);
                 }
             }
         }

@@ -40,8 +40,8 @@ def run(job):
             rows = []
             for pose in cpu_ref.compute_camera_poses(12, mins, maxs, cen):
                 view = cpu_ref.render_view(p64, pose, 224, stamp)
-                pre, _ = cpu_ref.preprocess_image_cv(view, 224, 0.05, "white", False)
-                rows.append(c.hu_batch(pre[None])["hulog7"][0])
+                _, mask = cpu_ref.preprocess_image_cv(view, 224, 0.05, "white", True)
+                rows.append(c.hu_batch(mask[None])["hulog7"][0])
             rows = np.stack(rows).astype(np.float32)
             np.concatenate([rows.mean(axis=0), rows.std(axis=0)])
     elif kind == "tail":
