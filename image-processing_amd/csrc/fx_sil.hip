@@ -1089,17 +1089,15 @@ __global__ __launch_bounds__(FX_BLOCK, 5) void sil_mask_kernel(SilArgs A)
 
             SIL_TICK(3);
             // ---- box of the external contour with the largest contourArea (reference :198-221).
-            // The external contours are the 8-connected components of the mask with its holes filled.  Most
-            // masks have no hole, and then the mask's own components are those: label the mask as it is, count
-            // its components C, and take the Euler number E (components minus holes) from the 2 x 2 windows
-            // around the corners of the pixel grid: 4 E = #(one pixel set) - #(three set) - 2 #(a diagonal pair).
+            // The external contours are the 8-connected components of the mask with its holes filled.  Many
+            // masks have no hole, and then the mask's own components are those.  The Euler number E (components
+            // minus holes) follows from the 2 x 2 windows around the corners of the pixel grid:
+            // 4 E = #(one pixel set) - #(three set) - 2 #(a diagonal pair).  E <= 0 means holes for certain;
+            // otherwise the mask is labelled as it is, and it has no hole exactly when it has E components.
             SIL_TICK(14);
-            SilRuns fg = sil_label(mA, H, wcH, GH.dv, wpr, true, pre, s_scan, &s_v[SV_NRUNS], s_runs, glob_runs, A.run_cap);
             const int wcV = (W + 32) >> 5;  // corners x = 0 .. W
             {
                 int e4 = 0;
-                for (int r = t; r < fg.n; r += FX_BLOCK)
-                    e4 -= fg.parent[r] == (uint32_t)r ? 4 : 0;
                 for (int vi = t; vi < (H + 1) * wcV; vi += FX_BLOCK) {
                     const int vy = sil_div(vi, dvV), w = vi - vy * wcV;
                     const uint32_t *ru = mA + (vy - 1) * wpr, *rd = mA + vy * wpr;
@@ -1115,12 +1113,29 @@ __global__ __launch_bounds__(FX_BLOCK, 5) void sil_mask_kernel(SilArgs A)
                 for (int o = FX_WAVE / 2; o > 0; o >>= 1)
                     e4 += __shfl_xor(e4, o, FX_WAVE);
                 if (fx_lane() == 0 && e4)
-                    atomicAdd(&s_v[SV_HOLES4], e4);   // 4 (E - C) = -4 holes
+                    atomicAdd(&s_v[SV_HOLES4], e4);
             }
             __syncthreads();
+            SilRuns fg;
+            fg.parent = fg.val = nullptr;
+            fg.n = 0;
+            bool filled = s_v[SV_HOLES4] <= 0;   // the hole-filling path is needed (or the mask is empty)
+            if (!filled) {
+                fg = sil_label(mA, H, wcH, GH.dv, wpr, true, pre, s_scan, &s_v[SV_NRUNS], s_runs, glob_runs, A.run_cap);
+                int roots = 0;
+                for (int r = t; r < fg.n; r += FX_BLOCK)
+                    roots += fg.parent[r] == (uint32_t)r ? 4 : 0;
+#pragma unroll
+                for (int o = FX_WAVE / 2; o > 0; o >>= 1)
+                    roots += __shfl_xor(roots, o, FX_WAVE);
+                if (fx_lane() == 0 && roots)
+                    atomicSub(&s_v[SV_HOLES4], roots);   // 4 (E - C) = -4 holes
+                __syncthreads();
+                filled = s_v[SV_HOLES4] != 0;
+            }
             SIL_TICK(15);
             const uint32_t *mF = mA;   // the mask whose components are the external contours
-            if (s_v[SV_HOLES4] != 0) {
+            if (filled) {
             // (1) background runs, 4-connected; those that reach the image frame are the outside
             for (int wi = t; wi < H * wcH; wi += FX_BLOCK) {
                 const int y = sil_div(wi, GH.dv), w = wi - y * wcH;
