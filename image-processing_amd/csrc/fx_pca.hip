@@ -30,6 +30,8 @@ struct PcaArgs {
     double *eig;
     int slab_floats;  // LDS floats per wave (wave kernel)
     const int32_t *n_sets_dev;  // when set: the number of entries of set_ids, known on the device only
+    int32_t *redo_list;         // pca_sets_full_kernel: sets left to pca_sets_redo_kernel, and their number
+    int32_t *redo_count;
 };
 
 constexpr int HIST_MAX = 64;
@@ -327,7 +329,7 @@ __device__ __forceinline__ void wave_sum9(double (&v)[9], double *slab)
 // bytes per load instruction of the wave); 4 % slower than the 16-byte loads of
 // the aligned layout, where lane l holds the four-point groups l, l + 64, ...
 template <int PPL, bool RAGGED, int NW>
-__global__ __launch_bounds__(FX_WAVE *NW, FX_PCA_WAVES) void pca_sets_reg_kernel(PcaArgs A)
+__device__ __forceinline__ void pca_sets_reg_body(const PcaArgs &A, const int64_t blk, const int64_t n_sets)
 {
     // The histogram of a wave is kept in HIST_COPIES copies, lane l counting in
     // copy l % HIST_COPIES: most points of a set fall into a few bins, and 64
@@ -338,10 +340,7 @@ __global__ __launch_bounds__(FX_WAVE *NW, FX_PCA_WAVES) void pca_sets_reg_kernel
     __shared__ double red_all[NW][RED9_WORDS];
     __shared__ double cov_all[NW][6], eig_all[NW][6];
     const int lane = fx_lane(), wave = fx_wave();
-    const int64_t slot = (int64_t)blockIdx.x * NW + wave;
-    const int64_t n_sets = A.n_sets_dev ? (int64_t)*A.n_sets_dev : A.n_sets;
-    if ((int64_t)blockIdx.x * NW >= n_sets)
-        return;  // a surplus block of a launch sized by an upper bound (the whole block leaves, before any barrier)
+    const int64_t slot = blk * NW + wave;
     // a wave past the last set stays for the block barriers: it works on the first set and writes nothing
     const bool in_range = slot < n_sets;
     const SetView sv = resolve_set(A, in_range ? slot : 0);
@@ -465,7 +464,7 @@ __global__ __launch_bounds__(FX_WAVE *NW, FX_PCA_WAVES) void pca_sets_reg_kernel
             cov_all[wave][lane] = c * inv;
         }
         __syncthreads();
-        if (wave == (int)(blockIdx.x % NW) && lane < NW) {
+        if (wave == (int)(blk % NW) && lane < NW) {
             const double *c = cov_all[lane];
             double l3[3], w3[3];
             fx_eig3<true>(c[0], c[1], c[2], c[3], c[4], c[5], l3, w3);
@@ -576,6 +575,26 @@ __global__ __launch_bounds__(FX_WAVE *NW, FX_PCA_WAVES) void pca_sets_reg_kernel
     }
 }
 
+template <int PPL, bool RAGGED, int NW>
+__global__ __launch_bounds__(FX_WAVE *NW, FX_PCA_WAVES) void pca_sets_reg_kernel(PcaArgs A)
+{
+    const int64_t n_sets = A.n_sets_dev ? (int64_t)*A.n_sets_dev : A.n_sets;
+    if ((int64_t)blockIdx.x * NW >= n_sets)
+        return;  // a surplus block of a launch sized by an upper bound (the whole block leaves, before any barrier)
+    pca_sets_reg_body<PPL, RAGGED, NW>(A, blockIdx.x, n_sets);
+}
+
+// The sets pca_sets_full_kernel hands back (A.set_ids, their number in *A.n_sets_dev): a small grid walks the list.
+template <int PPL, int NW>
+__global__ __launch_bounds__(FX_WAVE *NW, FX_PCA_WAVES) void pca_sets_redo_kernel(PcaArgs A)
+{
+    const int64_t n_sets = (int64_t)*A.n_sets_dev;
+    for (int64_t blk = blockIdx.x; blk * NW < n_sets; blk += gridDim.x) {
+        pca_sets_reg_body<PPL, false, NW>(A, blk, n_sets);
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------- full sets: the C4 kernel
 // Equal-sized, 16-byte aligned 3-D sets of exactly 64 * PPL points (the
 // pipeline's 1024-point clouds): no per-point predicates, 1 / n and
@@ -584,7 +603,8 @@ __global__ __launch_bounds__(FX_WAVE *NW, FX_PCA_WAVES) void pca_sets_reg_kernel
 // (the candidates for the exact maximum, points within rounding of a bin
 // edge): instead of a float64 branch per point index (thirty-two inlined
 // copies, the widened coordinates kept alive for them) such points are
-// appended to a short LDS list and evaluated afterwards, a lane per point.
+// appended to a short LDS list and evaluated afterwards, a lane per point;
+// and one pass over the points settles maximum and bins together.
 // The float32 pre-value of the projection is three FMAs on the raw
 // coordinates (v.x - v.mean); its error bound grows with the distance of the
 // set from the origin (sets far away send more points to the float64 path,
@@ -727,8 +747,7 @@ __global__ __launch_bounds__(FX_WAVE *NW, FX_PCA_WAVES) void pca_sets_full_kerne
         };
         // float32 value: v.x - v.mean in three FMAs.  Each of its five roundings is relative to a partial sum
         // of at most |v.mean| + |v| |x| <= w (|mean|_1 + |mean|_2 + reach): eps32 bounds the total generously.
-        // It settles every point that is not within eps32 of a decision; those few are decided in float64,
-        // one point index at a time for the whole wave, so that the float64 code exists once.
+        // It settles every point that is not within eps32 of a decision; those few are decided in float64.
         const float w32 = scale ? (float)(1.0 / rmax) : 1.0f;
         const float vx32 = (float)v1[0] * w32, vy32 = (float)v1[1] * w32, vz32 = (float)v1[2] * w32;
         const float c32 = (float)(fma(v1[2], mz, fma(v1[1], my, v1[0] * mx))) * w32;
@@ -739,7 +758,6 @@ __global__ __launch_bounds__(FX_WAVE *NW, FX_PCA_WAVES) void pca_sets_full_kerne
         for (int i = 0; i < PPL; i++)
             top32 = fmaxf(top32, fabsf(fmaf(z[i], vz32, fmaf(y[i], vy32, fmaf(x[i], vx32, -c32)))));
         top32 = fx_wave_max_f32_dpp(top32);
-        const float cand32 = top32 - 2.0f * eps32;  // the exact maximum is among the points at or above this
         // Points that float32 cannot settle are appended to a short list in LDS (a wave-uniform branch per point
         // index, taken for about one index in sixteen) and evaluated in float64 afterwards, a lane per listed
         // point: the float64 code exists once and runs without divergence.
@@ -755,72 +773,61 @@ __global__ __launch_bounds__(FX_WAVE *NW, FX_PCA_WAVES) void pca_sets_full_kerne
             }
             n_slow += __builtin_popcountll(mask);
         };
-        double top = 0.0;
-        auto drain_top = [&]() {
+        auto list_sync = [&]() {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            for (int e = lane; e < n_slow; e += FX_WAVE)
-                top = fmax(top, proj(slow_list[3 * e], slow_list[3 * e + 1], slow_list[3 * e + 2]));
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            n_slow = 0;
         };
-#pragma unroll
-        for (int i = 0; i < PPL; i++) {
-            const float p = fabsf(fmaf(z[i], vz32, fmaf(y[i], vy32, fmaf(x[i], vx32, -c32))));
-            const unsigned long long mask = __builtin_amdgcn_ballot_w64(p >= cand32);
-            if (mask) {
-                if (n_slow > SLOW_CAP)   // degenerate sets (all points at the same |projection|): work the list off first
-                    drain_top();
-                append(mask, x[i], y[i], z[i]);
-            }
-        }
-        drain_top();
-        top = fx_wave_max_f64_dpp(top);
-
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (top > 0.0) {
-            const double step = top / (double)nb;
-            const double inv_step = (double)nb / top;
-            // q = |projection| / step in float32 with the scale folded into the direction; a point whose q lies
-            // within `margin` of an integer (a bin edge; the top edge included, since q cannot exceed n_bins by
-            // more than its rounding) is left to float64 and counted in the pad word of the histogram for now
-            const float inv32 = (float)inv_step;
+        list_sync();
+        // One pass settles the bins.  The float32 maximum is within eps32 of the exact one, so bins taken with
+        // the scale n_bins / top32 are those of the exact scale for every point whose q = |projection| * scale
+        // stays `margin` away from an integer; the others -- the candidates for the exact maximum among them,
+        // which all lie within the margin below n_bins -- go to the list.  The exact maximum then comes from the
+        // listed points, and they are binned with it in float64.
+        bool redo = !(top32 > 8.0f * eps32);   // projections at rounding level: everything in float64, below
+        double top = 0.0;
+        if (!redo) {
+            const float inv32 = (float)nb / top32;
             const float qx = vx32 * inv32, qy = vy32 * inv32, qz = vz32 * inv32, qc = c32 * inv32;
-            const float margin = 2.0f * (eps32 + 3e-7f * top32) * inv32 + 1e-5f * (float)nb;
-            auto drain_bins = [&]() {
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                for (int e = lane; e < n_slow; e += FX_WAVE)
-                    atomicAdd(&my_hist[fx_hist_bin(proj(slow_list[3 * e], slow_list[3 * e + 1], slow_list[3 * e + 2]), step,
-                                                   inv_step, nb)], 1u);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                n_slow = 0;
-            };
+            const float margin = (3.0f * eps32 + 6e-7f * top32) * inv32 + 1e-5f * (float)nb;
 #pragma unroll
             for (int i = 0; i < PPL; i++) {
                 const float q = fabsf(fmaf(z[i], qz, fmaf(y[i], qy, fmaf(x[i], qx, -qc))));
                 const bool slow = fabsf(q - rintf(q)) < margin;
                 atomicAdd(&my_hist[slow ? HIST_MAX : (int)q], 1u);
                 const unsigned long long mask = __builtin_amdgcn_ballot_w64(slow);
-                if (mask) {
+                if (mask && !redo) {
                     if (n_slow > SLOW_CAP)
-                        drain_bins();
-                    append(mask, x[i], y[i], z[i]);
+                        redo = true;   // degenerate sets (most points at one |projection|): the list would overflow
+                    else
+                        append(mask, x[i], y[i], z[i]);
                 }
             }
-            drain_bins();
-            if (live && lane < nb) {
-                uint32_t h = 0;
+        }
+        // Sets the single pass cannot take (projections at rounding level, or so many points at one
+        // |projection| that the list overflows) are handed to pca_sets_redo_kernel.
+        if (redo) {
+            if (live && lane == 0)
+                A.redo_list[atomicAdd(A.redo_count, 1)] = (int32_t)set;
+            return;   // after the block's last barrier
+        }
+        list_sync();
+        for (int e = lane; e < n_slow; e += FX_WAVE)
+            top = fmax(top, proj(slow_list[3 * e], slow_list[3 * e + 1], slow_list[3 * e + 2]));
+        top = fx_wave_max_f64_dpp(top);
+        {
+            const double step = top / (double)nb;
+            const double inv_step = (double)nb / top;
+            for (int e = lane; e < n_slow; e += FX_WAVE)
+                atomicAdd(&my_hist[fx_hist_bin(proj(slow_list[3 * e], slow_list[3 * e + 1], slow_list[3 * e + 2]), step,
+                                               inv_step, nb)], 1u);
+        }
+        list_sync();
+        if (live && lane < nb) {
+            uint32_t h = 0;
 #pragma unroll
-                for (int k = 0; k < HIST_COPIES; k++)
-                    h += hist[k * HIST_PITCH + lane];
-                A.out[set * width + 9 + lane] = (float)h / (float)n;
-            }
-        } else if (live && lane < nb) {
-            A.out[set * width + 9 + lane] = lane == 0 ? 1.0f : 0.0f;
+            for (int k = 0; k < HIST_COPIES; k++)
+                h += hist[k * HIST_PITCH + lane];
+            A.out[set * width + 9 + lane] = (float)h / (float)n;
         }
         if (live && lane < 9)
             A.out[set * width + lane] = (float)head_mine;
@@ -1206,7 +1213,13 @@ int launch_full_sets(const PcaArgs &A, hipStream_t s)
     const int64_t blocks = (A.n_sets + NW - 1) / NW;
     FX_REQUIRE(blocks <= 0x7fffffffLL, "fx_pca_batch_f32: too many sets for one launch");
     const int64_t n = (int64_t)FX_WAVE * PPL;
+    FX_REQUIRE(A.redo_list && A.redo_count, "fx_pca_batch_f32: no list for the sets to redo");
+    FX_HIP_CHECK(hipMemsetAsync(A.redo_count, 0, sizeof(int32_t), s));
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(FX_WAVE * NW), 0, s, A, 1.0 / (double)n, 1.0 / (double)(n - 1));
+    PcaArgs R = A;
+    R.set_ids = A.redo_list;
+    R.n_sets_dev = A.redo_count;
+    hipLaunchKernelGGL((pca_sets_redo_kernel<PPL, NW>), dim3((unsigned)(blocks < 256 ? blocks : 256)), dim3(FX_WAVE * NW), 0, s, R);
     FX_HIP_CHECK(hipGetLastError());
     return FX_OK;
 }
@@ -1529,11 +1542,21 @@ extern "C" int fx_pca_batch_f32(const float *d_pts, const int64_t *d_offsets, in
     A.eig = d_eig;
     A.slab_floats = 0;
     A.n_sets_dev = nullptr;
+    A.redo_list = nullptr;
+    A.redo_count = nullptr;
     FxCallGuard guard(s);
 
     if (!d_offsets) {
-        FxProfileScope prof(s);
         const bool reg_ok = dims == 3 && N >= 3 && N <= REG_SET_MAX_POINTS;
+        if (reg_ok && (N == 256 || N == 512 || N == 1024) && (uintptr_t)d_pts % 16 == 0) {
+            // pca_sets_full_kernel's list of sets for pca_sets_redo_kernel
+            int32_t *redo = (int32_t *)guard.scratch(((size_t)B + 64) * sizeof(int32_t), 0);
+            if (!redo)
+                return FX_ENOMEM;
+            A.redo_count = redo;
+            A.redo_list = redo + 64;
+        }
+        FxProfileScope prof(s);
         if (reg_ok)
             return launch_reg_sets(A, N, N % 4 != 0 || (uintptr_t)d_pts % 16 != 0, s);
         if (N <= WAVE_SET_MAX_POINTS)
