@@ -610,7 +610,8 @@ __global__ __launch_bounds__(FX_WAVE *NW, FX_PCA_WAVES) void pca_sets_redo_kerne
 // set from the origin (sets far away send more points to the float64 path,
 // results are the same).
 template <int PPL, int NW, bool NORMALIZE>
-__global__ __launch_bounds__(FX_WAVE *NW, FX_PCA_WAVES) void pca_sets_full_kernel(PcaArgs A, double inv_n, double inv_nm1)
+// (sets of 512 points leave room for a fifth wave per SIMD: 12 % faster there; at 1024 points it would spill)
+__global__ __launch_bounds__(FX_WAVE *NW, PPL <= 8 ? 5 : FX_PCA_WAVES) void pca_sets_full_kernel(PcaArgs A, double inv_n, double inv_nm1)
 {
     constexpr int HIST_COPIES = 8, HIST_PITCH = HIST_MAX + 1;
     __shared__ uint32_t hist_all[NW][HIST_COPIES * HIST_PITCH];

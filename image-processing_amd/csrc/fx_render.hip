@@ -21,7 +21,8 @@ namespace {
 
 constexpr int RENDER_MAX_K = 7;        // stamps up to 7 x 7 cells (49 lanes of the stamping wave)
 constexpr int RENDER_CHUNK = 2048;     // snapped positions kept in LDS at a time
-constexpr int RENDER_MAX_RES = 384;    // canvas bytes in LDS: 384^2 = 144 KiB
+constexpr int RENDER_MAX_RES = 4096;
+constexpr int RENDER_CANVAS_LDS = 144 * 1024;   // canvas bytes a block keeps in LDS: views above 384 x 384 are cut into bands of rows
 #ifndef RENDER_WAVES_N
 #define RENDER_WAVES_N 8
 #endif
@@ -40,6 +41,8 @@ struct RenderArgs {
     int marker;               // marker gray value: 0 on a white background, 255 on a black one
     unsigned char stamp[RENDER_MAX_K * RENDER_MAX_K];
     uint8_t *out;             // [B][V][res][res]
+    int band_rows;            // canvas rows per block (a multiple of 8, or res)
+    int nbands;               // blocks per view
 };
 
 __device__ __forceinline__ double block_minmax(double v, bool is_max, double *red)
@@ -80,10 +83,13 @@ __global__ __launch_bounds__(RENDER_THREADS) void render_views_kernel(RenderArgs
     __shared__ uint32_t s_list[RENDER_WAVES][FX_WAVE];   // per wave: its points of the current batch
     uint8_t *canvas = lds_raw;
     const int t = threadIdx.x;
-    const int64_t bv = blockIdx.x;
+    const int64_t bv = blockIdx.x / A.nbands;
+    const int band = (int)(blockIdx.x - bv * A.nbands);
     const int64_t b = bv / A.V;
     const int res = A.res;
-    const int npx = res * res;
+    // the block's band of canvas rows [r0, r1): bands are disjoint, so each keeps the point order on its own
+    const int r0 = band * A.band_rows, r1 = r0 + A.band_rows < res ? r0 + A.band_rows : res;
+    const int npx = (r1 - r0) * res;
     const int64_t lo = A.offsets[b], n = A.offsets[b + 1] - lo;
     const float *pts = A.pts + lo * 3;
     const double *cam = A.cam + bv * 9;
@@ -150,8 +156,8 @@ __global__ __launch_bounds__(RENDER_THREADS) void render_views_kernel(RenderArgs
     auto stamp_cell = [&](uint32_t rc) {
         const int row = (int)(rc >> 16) - 1024 + cell_dy;
         const int col = (int)(rc & 0xFFFFu) - 1024 + cell_dx;
-        if (alpha != 0u && row >= 0 && row < res && owner(row) == wave && col >= 0 && col < res) {
-            const int at = row * res + col;
+        if (alpha != 0u && row >= r0 && row < r1 && owner(row) == wave && col >= 0 && col < res) {
+            const int at = (row - r0) * res + col;
             const uint32_t p = canvas[at];
             canvas[at] = (uint8_t)(alpha == 255u ? marker : agg_blend(p, marker, alpha, den, inv_den));
         }
@@ -176,7 +182,8 @@ __global__ __launch_bounds__(RENDER_THREADS) void render_views_kernel(RenderArgs
             const uint32_t mine = i < m ? s_snap[i] : 0u;
             const int my_row = (int)(mine >> 16) - 1024;
             // a stamp of at most 7 rows touches one or two stripes
-            const bool take = i < m && (owner(my_row - half + 1024) == wave || owner(my_row + half + 1024) == wave);
+            const bool take = i < m && my_row + half >= r0 && my_row - half < r1 &&
+                              (owner(my_row - half + 1024) == wave || owner(my_row + half + 1024) == wave);
             unsigned long long todo = __ballot(take);
             if (G < 2) {
                 while (todo) {
@@ -210,7 +217,7 @@ __global__ __launch_bounds__(RENDER_THREADS) void render_views_kernel(RenderArgs
         }
     }
     __syncthreads();
-    uint8_t *out = A.out + bv * (int64_t)npx;
+    uint8_t *out = A.out + bv * (int64_t)res * res + (int64_t)r0 * res;
     if ((npx & 15) == 0 && ((uintptr_t)out & 15) == 0) {
         for (int i = t * 16; i < npx; i += RENDER_THREADS * 16)
             *reinterpret_cast<uint4 *>(out + i) = *reinterpret_cast<const uint4 *>(canvas + i);
@@ -409,11 +416,16 @@ extern "C" int fx_render_views_u8(const float *d_pts, const int64_t *d_offsets, 
     for (int i = 0; i < RENDER_MAX_K * RENDER_MAX_K; i++)
         A.stamp[i] = i < K * K ? stamp[i] : 0;
     A.out = d_out;
-    const size_t lds = ((size_t)resolution * resolution + 15) & ~(size_t)15;
+    A.band_rows = resolution;
+    if ((size_t)resolution * resolution > (size_t)RENDER_CANVAS_LDS)
+        A.band_rows = (RENDER_CANVAS_LDS / resolution) & ~7;   // whole stripes of eight rows
+    A.nbands = (resolution + A.band_rows - 1) / A.band_rows;
+    FX_REQUIRE(B * V * A.nbands <= 0x7fffffffLL, "fx_render_views_u8: too many views for one launch");
+    const size_t lds = ((size_t)A.band_rows * resolution + 15) & ~(size_t)15;
     if (lds > 48 * 1024)
         FX_HIP_CHECK(hipFuncSetAttribute((const void *)render_views_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     FxProfileScope prof((hipStream_t)stream);
-    hipLaunchKernelGGL(render_views_kernel, dim3((unsigned)(B * V)), dim3(RENDER_THREADS), lds, (hipStream_t)stream, A);
+    hipLaunchKernelGGL(render_views_kernel, dim3((unsigned)(B * V * A.nbands)), dim3(RENDER_THREADS), lds, (hipStream_t)stream, A);
     FX_HIP_CHECK(hipGetLastError());
     return FX_OK;
 }

@@ -163,12 +163,77 @@ def camera_table(bounds: np.ndarray, n_views: int, resolution: int, radius_facto
     return cam, np.ascontiguousarray(scale)
 
 
+_MEASURED_STAMPS: Dict[float, np.ndarray] = {}
+MAX_STAMP_SIDE = 7   # the kernel keeps a stamp in the lanes of a wave: at most 7 x 7 cells
+
+
+def measure_marker_stamp(s: float) -> np.ndarray:
+    """Coverage stamp of one round marker of area `s` points^2 at dpi 100, taken from matplotlib's Agg backend
+    itself (the library the reference's renderer draws with): the marker is drawn on figures of four gray
+    levels, and the alpha of every cell is the only value consistent with Agg's blend on all four.  Agg
+    rasterises a scatter marker once and stamps it at whole-pixel positions, so one measurement serves every
+    point.  Used for marker sizes that are not tabulated in marker_stamps.py."""
+    try:
+        import matplotlib
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+    except Exception as e:  # pragma: no cover - depends on the installation
+        raise ValueError(f"point_size {s}: not tabulated, and matplotlib is not importable to measure it ({e})")
+    from io import BytesIO
+    from PIL import Image
+
+    def blend(p: int, a: int) -> int:   # Agg's plain RGBA blend of a black marker onto an opaque gray p
+        if a == 0:
+            return p
+        r = p * 255
+        return ((((0 << 8) - r) * a + (r << 8)) & 0xFFFFFFFF) // (((a + 255) << 8) - a * 255)
+
+    res, R = 64, 15
+    cands = None
+    for gray in (255, 200, 128, 64):
+        fig = plt.figure(figsize=(res / 100.0, res / 100.0), dpi=100, facecolor=(gray / 255.0,) * 3)
+        ax = fig.add_subplot(111)
+        ax.scatter([32.2], [31.7], s=s, color=(0, 0, 0), marker="o", linewidths=0, alpha=1.0)
+        ax.axis("off")
+        ax.set_frame_on(False)
+        ax.set_xlim(0, res)
+        ax.set_ylim(0, res)
+        ax.set_aspect("equal", adjustable="box")
+        fig.subplots_adjust(0, 0, 1, 1)
+        buf = BytesIO()
+        fig.canvas.print_png(buf)
+        buf.seek(0)
+        img = np.asarray(Image.open(buf).convert("RGB"))[:, :, 0].astype(int)
+        plt.close(fig)
+        win = img[32 - R:32 + R + 1, 32 - R:32 + R + 1]
+        table = {}
+        for a in range(256):
+            table.setdefault(blend(gray, a), set()).add(a)
+        sets = [[table.get(int(win[j, i]), set()) for i in range(2 * R + 1)] for j in range(2 * R + 1)]
+        cands = sets if cands is None else [[cands[j][i] & sets[j][i] for i in range(2 * R + 1)] for j in range(2 * R + 1)]
+    if not all(len(c) == 1 for row in cands for c in row):
+        raise ValueError(f"point_size {s}: the marker's coverage could not be measured")
+    al = np.array([[min(c) for c in row] for row in cands])
+    ys, xs = np.nonzero(al)
+    if ys.size == 0:
+        return np.zeros((1, 1), dtype=np.uint8)
+    k = int(max(np.abs(ys - R).max(), np.abs(xs - R).max()))
+    return al[R - k:R + k + 1, R - k:R + k + 1].astype(np.uint8)
+
+
 def marker_stamp(point_size: float) -> np.ndarray:
-    """Coverage stamp Agg draws for scatter(s=max(0.1, point_size)) at dpi 100."""
+    """Coverage stamp Agg draws for scatter(s=max(0.1, point_size)) at dpi 100: from the table of
+    marker_stamps.py, or measured from matplotlib once per size (the reference accepts any size)."""
     s = max(0.1, float(point_size))
-    if s not in STAMPS:
-        raise ValueError(f"point_size {point_size}: no marker stamp tabulated; available sizes: {sorted(STAMPS)}")
-    return np.array(STAMPS[s], dtype=np.uint8)
+    if s in STAMPS:
+        return np.array(STAMPS[s], dtype=np.uint8)
+    if s not in _MEASURED_STAMPS:
+        _MEASURED_STAMPS[s] = measure_marker_stamp(s)
+    stamp = _MEASURED_STAMPS[s]
+    if stamp.shape[0] > MAX_STAMP_SIDE:
+        raise ValueError(f"point_size {point_size}: a marker of {stamp.shape[0]} x {stamp.shape[0]} pixels; the device "
+                         f"renderer takes markers up to {MAX_STAMP_SIDE} x {MAX_STAMP_SIDE}")
+    return stamp
 
 
 def pack_clouds(clouds: Sequence[np.ndarray], device: torch.device):

@@ -361,7 +361,7 @@ int fx_binarize_ge_f64(const double *d_x, int64_t rows, int cols,
  * marker_value: 0 (bg_color "white") or 255 ("black": white markers; the
  * figure stays white because the axes patch is switched off, :344-349).
  * d_out: uint8 [B, V, resolution, resolution], the R = G = B channel of the
- * reference's image.  resolution <= 384.
+ * reference's image.  resolution <= 4096 (a view above 384 x 384 is drawn by several blocks, a band of rows each).
  *
  * fx_cloud_bounds_f32: per cloud min xyz, max xyz, mean xyz (float64 [B, 9])
  * as bbox_and_center :77-87 computes them from the float32 file values.

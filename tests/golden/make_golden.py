@@ -310,7 +310,9 @@ def make_render(ref: Path) -> None:
     specs = [(1024, 224, 2.0, "white", 12, (0, 4, 7, 11)), (1024, 224, 2.0, "white", 12, (1, 5, 9)),
              (300, 224, 1.0, "white", 12, (2, 6)), (2048, 128, 4.0, "white", 6, (0, 3)),
              (1024, 224, 8.0, "white", 12, (3, 10)), (5000, 300, 2.0, "white", 12, (0, 8)),
-             (1024, 224, 2.0, "black", 12, (0,)), (64, 96, 16.0, "white", 5, (0, 4)), (1, 64, 2.0, "white", 3, (0,))]
+             (1024, 224, 2.0, "black", 12, (0,)), (64, 96, 16.0, "white", 5, (0, 4)), (1, 64, 2.0, "white", 3, (0,)),
+             # marker sizes outside the stamp table: the host mirror measures those from matplotlib when asked
+             (700, 160, 2.5, "white", 4, (1,)), (300, 128, 7.0, "white", 4, (2,))]
     k = 0
     for ci, (n, res, ps, bg, views, chosen) in enumerate(specs):
         q, _ = np.linalg.qr(rng.normal(size=(3, 3)))

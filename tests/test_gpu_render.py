@@ -41,7 +41,7 @@ def test_batches_against_oracle(gpu, oracle):
         clouds.append(((rng.normal(size=(n, 3)) * np.exp(rng.uniform(-2, 1, size=3))) @ q.T + rng.normal(size=3) * 3).astype(np.float32))
     clouds.append(np.tile(np.array([[0.5, -1.0, 2.0]], dtype=np.float32), (30, 1)))
     clouds.append(np.c_[np.linspace(-1, 1, 200), np.zeros(200), np.zeros(200)].astype(np.float32))
-    for res, ps, views in ((224, 2.0, 12), (96, 5.0, 4), (384, 1.0, 3)):
+    for res, ps, views in ((224, 2.0, 12), (96, 5.0, 4), (384, 1.0, 3), (512, 2.0, 2), (700, 4.0, 2)):   # the last two: banded canvas
         got = rv.render_views_batch(clouds, views, res, ps).cpu().numpy()
         assert got.shape == (len(clouds), views, res, res)
         stamp = rv.marker_stamp(ps)
@@ -80,12 +80,12 @@ def test_bounds_poses_and_errors(gpu, oracle):
         for a, r in zip(mine, ref):
             for key in ("position", "lookat", "up"):
                 np.testing.assert_array_equal(a[key], r[key])
-    with pytest.raises(ValueError, match="no marker stamp"):
-        rv.render_views_batch(clouds[:1], 3, 64, 2.5)
+    with pytest.raises(ValueError, match="up to 7 x 7"):
+        rv.render_views_batch(clouds[:1], 3, 64, 400.0)
     with pytest.raises(ValueError, match="empty point cloud"):
         rv.render_views_batch([np.zeros((0, 3), np.float32)], 3, 64)
     with pytest.raises(pkg("_lib").FxError):
-        rv.render_views_batch(clouds[:1], 3, 1000)
+        rv.render_views_batch(clouds[:1], 3, 5000)
 
 
 def test_directory_run_and_views_feed_the_hu_path(gpu, tmp_path, oracle):
@@ -124,7 +124,7 @@ def test_directory_run_and_views_feed_the_hu_path(gpu, tmp_path, oracle):
 
 def test_one_bad_sample_does_not_take_the_batch_with_it(gpu, tmp_path):
     """The reference's worker catches per sample: a cloud the renderer refuses
-    (NaN coordinates, a marker size without a stamp) or a file that cannot be
+    (NaN coordinates, a marker too large for the device) or a file that cannot be
     read gets a "failed: ..." record and a line in read_errors.log; every other
     sample of the batch is rendered and gets its manifest row."""
     rv = pkg("render_views")
@@ -139,8 +139,8 @@ def test_one_bad_sample_does_not_take_the_batch_with_it(gpu, tmp_path):
     np.save(sampled / "e_good.npy", good[2])
     common = (str(out), 96, 4, 2.0, "white", False, False, 2.0, 42, True, str(reports))
     tasks = [(str(p),) + common for p in sorted(sampled.glob("*.npy"))]
-    # a task with a marker size that has no stamp: fails on the device side of the batch
-    tasks.append((str(sampled / "a_good.npy"), str(tmp_path / "views2"), 96, 4, 2.37, "white", False, False, 2.0, 42, True,
+    # a task with a marker the device renderer does not take: fails on the device side of the batch
+    tasks.append((str(sampled / "a_good.npy"), str(tmp_path / "views2"), 96, 4, 400.0, "white", False, False, 2.0, 42, True,
                   str(reports)))
     res = rv.render_samples(tasks)
     assert [r["success"] for r in res] == [True, False, True, False, True, False]

@@ -428,8 +428,14 @@ def test_camera_table_matches_the_per_cloud_poses():
     np.testing.assert_allclose(scale, want_scale, rtol=1e-15)
     assert [len(rv.view_angles(v)) for v in (1, 2, 3, 7, 12)] == [1, 2, 3, 7, 12]
     assert rv.marker_stamp(2.0).shape == (3, 3) and rv.marker_stamp(0.5).shape == (1, 1)
-    with pytest.raises(ValueError):
-        rv.marker_stamp(2.5)
+    # sizes outside the table are measured from matplotlib's Agg backend, as the table itself was
+    pytest.importorskip("matplotlib")
+    for s in (1.0, 2.0, 8.0):
+        np.testing.assert_array_equal(rv.measure_marker_stamp(s), rv.marker_stamp(s))
+    mid = rv.marker_stamp(2.5)
+    assert mid.shape == (3, 3) and mid[1, 1] == 255 and rv.marker_stamp(2.0)[0, 1] < mid[0, 1] < rv.marker_stamp(3.0)[0, 1]
+    with pytest.raises(ValueError, match="up to 7 x 7"):
+        rv.marker_stamp(400.0)
 
 
 def test_class_codes_follow_sorted_labels():
