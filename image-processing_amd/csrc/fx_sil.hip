@@ -249,6 +249,8 @@ __device__ __forceinline__ int sil_refl101(int i, int n)
     return i;
 }
 
+constexpr int SIL_CV_HIST_COPIES = 4, SIL_CV_HIST_PITCH = 257;
+
 template <bool ALIGNED>
 __global__ __launch_bounds__(FX_BLOCK) void sil_blur_cv_kernel(SilArgs A)
 {
@@ -261,16 +263,24 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_blur_cv_kernel(SilArgs A)
     const int nrows = H - r0 < A.tr ? H - r0 : A.tr;           // rows this tile writes
     const int trows = nrows + 2 * SIL_CV_HALO;
     uint16_t *tile = (uint16_t *)sil_smem;                                        // [tr + 4][Wp] sums along x
-    uint32_t *hist = (uint32_t *)(sil_smem + (size_t)(A.tr + 2 * SIL_CV_HALO) * Wp * 2);  // [256]
+    // the histogram in SIL_CV_HIST_COPIES copies, lane l counting in copy l % copies: neighbouring pixels mostly share
+    // a few gray levels, and lanes adding to the same word serialise; the pitch puts a level's copies into different banks
+    uint32_t *hist = (uint32_t *)(sil_smem + (size_t)(A.tr + 2 * SIL_CV_HALO) * Wp * 2);  // [copies][257]
+    uint32_t *my_hist = hist + (threadIdx.x % SIL_CV_HIST_COPIES) * SIL_CV_HIST_PITCH;
     const uint8_t *src = A.img + b * A.stride;
-    hist[threadIdx.x] = 0;
+    for (int k = threadIdx.x; k < SIL_CV_HIST_COPIES * SIL_CV_HIST_PITCH; k += FX_BLOCK)
+        hist[k] = 0;
+    // a tile row keeps the first eight sums of every 16-pixel chunk side by side, then the second eight: the two
+    // 16-byte stores of the row pass are then contiguous over the lanes
+    const int half_row = Wp >> 1;
 
     // along x: 16 pixels + 2 on each side in registers; tile row i is image row reflect(r0 - 2 + i)
     for (int it = threadIdx.x; it < trows * cpr; it += FX_BLOCK) {
         const int i = it / cpr, c = it - i * cpr;
         const uint8_t *row = src + (int64_t)sil_refl101(r0 - SIL_CV_HALO + i, H) * A.pitch;
         const int x0 = c * 16;
-        uint4 *dst = (uint4 *)(tile + (size_t)i * Wp + x0);
+        uint4 *dst_lo = (uint4 *)(tile + (size_t)i * Wp + 8 * c);
+        uint4 *dst_hi = (uint4 *)(tile + (size_t)i * Wp + half_row + 8 * c);
         if (ALIGNED) {   // W is a multiple of 16 (so at least 16) and rows are 16-byte aligned
             // Pairs of neighbouring pixels as two 16-bit fields of a word, P[j] = (pixel j - 2, pixel j - 1)
             // counted from the chunk's first pixel: one byte permute each.  A sum of the five taps is at most
@@ -296,8 +306,8 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_blur_cv_kernel(SilArgs A)
 #pragma unroll
             for (int k = 0; k < 8; k++)
                 o[k] = P[2 * k] + P[2 * k + 4] + 4u * (P[2 * k + 1] + P[2 * k + 3]) + 6u * P[2 * k + 2];
-            dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
-            dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+            *dst_lo = make_uint4(o[0], o[1], o[2], o[3]);
+            *dst_hi = make_uint4(o[4], o[5], o[6], o[7]);
         } else {
             uint32_t v[20];
 #pragma unroll
@@ -310,62 +320,68 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_blur_cv_kernel(SilArgs A)
                 const uint32_t hi = v[k + 1] + v[k + 5] + 4u * (v[k + 2] + v[k + 4]) + 6u * v[k + 3];
                 o[k >> 1] = lo | (hi << 16);
             }
-            dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
-            dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+            *dst_lo = make_uint4(o[0], o[1], o[2], o[3]);
+            *dst_hi = make_uint4(o[4], o[5], o[6], o[7]);
         }
     }
     __syncthreads();
 
-    // along y: a thread takes four neighbouring columns (two packed pairs of 16-bit sums; the largest total,
-    // 255 * 256 + 128, still fits 16 bits, so both halves of a word are summed at once) and a stretch of rows
-    const int quads = Wp >> 2;
-    int segs = FX_BLOCK / quads;
+    // along y: a thread takes eight neighbouring columns (one 16-byte half chunk of the tile: four packed pairs of
+    // 16-bit sums; the largest total, 255 * 256 + 128, still fits 16 bits, so both halves of a word are summed
+    // at once) and a stretch of rows.  Lane j of a row takes the tile's j-th half chunk, so a wave's reads are
+    // contiguous.
+    const int octs = Wp >> 3;
+    int segs = FX_BLOCK / octs;
     segs = segs < 1 ? 1 : segs;
     const int rps = (nrows + segs - 1) / segs;
     uint8_t *out = A.blur + b * (int64_t)H * W;
-    const bool row_dwords = (W & 3) == 0;
-    for (int it = threadIdx.x; it < quads * segs; it += FX_BLOCK) {
-        const int q = it % quads, y0 = (it / quads) * rps;
+    const bool row_qwords = (W & 7) == 0;
+    for (int it = threadIdx.x; it < octs * segs; it += FX_BLOCK) {
+        const int j = it % octs, y0 = (it / octs) * rps;
         const int y1 = y0 + rps < nrows ? y0 + rps : nrows;
-        if (y0 >= y1 || 4 * q >= W)
+        const int x = j < cpr ? 16 * j : 16 * (j - cpr) + 8;   // first column of the half chunk
+        if (y0 >= y1 || x >= W)
             continue;
-        const uint16_t *col = tile + 4 * q;
-        auto ld = [&](int i) { return *(const uint2 *)(col + (size_t)i * Wp); };
-        uint2 c0 = ld(y0), c1 = ld(y0 + 1), c2 = ld(y0 + 2), c3 = ld(y0 + 3);
-        uint32_t prev = 0, rep = 0;
+        const uint16_t *col = tile + 8 * j;
+        auto ld = [&](int i) { return *(const uint4 *)(col + (size_t)i * Wp); };
+        uint4 c0 = ld(y0), c1 = ld(y0 + 1), c2 = ld(y0 + 2), c3 = ld(y0 + 3);
+        uint32_t prev_lo = 0, prev_hi = 0, rep = 0;
+        const int live = W - x;  // columns of this half chunk inside the image
         auto flush = [&]() {
             if (!rep)
                 return;
-            const uint32_t p0 = prev & 255u, p1 = (prev >> 8) & 255u, p2 = (prev >> 16) & 255u, p3 = prev >> 24;
-            const int live = W - 4 * q;  // columns of this quad inside the image
-            if (live >= 4 && p0 == p1 && p0 == p2 && p0 == p3) {
-                atomicAdd(&hist[p0], 4u * rep);
+            const uint32_t p0 = prev_lo & 255u;
+            if (live >= 8 && prev_lo == p0 * 0x01010101u && prev_hi == prev_lo) {
+                atomicAdd(&my_hist[p0], 8u * rep);
             } else {
-                atomicAdd(&hist[p0], rep);
-                if (live > 1)
-                    atomicAdd(&hist[p1], rep);
-                if (live > 2)
-                    atomicAdd(&hist[p2], rep);
-                if (live > 3)
-                    atomicAdd(&hist[p3], rep);
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    if (k < live)
+                        atomicAdd(&my_hist[((k < 4 ? prev_lo : prev_hi) >> (8 * (k & 3))) & 255u], rep);
             }
             rep = 0;
         };
+        auto pack = [](uint32_t ta, uint32_t tb) {
+            return ((ta >> 8) & 255u) | ((ta >> 24) << 8) | (((tb >> 8) & 255u) << 16) | ((tb >> 24) << 24);
+        };
         for (int y = y0; y < y1; y++) {
-            const uint2 c4 = ld(y + 4);
+            const uint4 c4 = ld(y + 4);
             const uint32_t ta = c0.x + c4.x + 4u * (c1.x + c3.x) + 6u * c2.x + 0x00800080u;
             const uint32_t tb = c0.y + c4.y + 4u * (c1.y + c3.y) + 6u * c2.y + 0x00800080u;
-            const uint32_t o = ((ta >> 8) & 255u) | ((ta >> 24) << 8) | (((tb >> 8) & 255u) << 16) | ((tb >> 24) << 24);
-            uint8_t *po = out + (int64_t)(r0 + y) * W + 4 * q;
-            if (row_dwords) {
-                *(uint32_t *)po = o;
+            const uint32_t tc = c0.z + c4.z + 4u * (c1.z + c3.z) + 6u * c2.z + 0x00800080u;
+            const uint32_t td = c0.w + c4.w + 4u * (c1.w + c3.w) + 6u * c2.w + 0x00800080u;
+            const uint32_t o_lo = pack(ta, tb), o_hi = pack(tc, td);
+            uint8_t *po = out + (int64_t)(r0 + y) * W + x;
+            if (row_qwords) {
+                *(uint2 *)po = make_uint2(o_lo, o_hi);
             } else {
-                for (int k = 0; k < 4 && 4 * q + k < W; k++)
-                    po[k] = (uint8_t)(o >> (8 * k));
+                for (int k = 0; k < 8 && k < live; k++)
+                    po[k] = (uint8_t)((k < 4 ? o_lo : o_hi) >> (8 * (k & 3)));
             }
-            if (o != prev) {
+            if (o_lo != prev_lo || o_hi != prev_hi) {
                 flush();
-                prev = o;
+                prev_lo = o_lo;
+                prev_hi = o_hi;
             }
             rep++;
             c0 = c1;
@@ -376,7 +392,10 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_blur_cv_kernel(SilArgs A)
         flush();
     }
     __syncthreads();
-    const uint32_t h = hist[threadIdx.x];
+    uint32_t h = 0;
+#pragma unroll
+    for (int k = 0; k < SIL_CV_HIST_COPIES; k++)
+        h += hist[k * SIL_CV_HIST_PITCH + threadIdx.x];
     if (h)
         atomicAdd(&A.hist[b * 256 + threadIdx.x], h);
 }
@@ -728,8 +747,15 @@ __device__ SilRuns sil_label(const uint32_t *m, int rows, int wc, SilDiv dv, int
     // flat forest, where a root is one step away, and the few new links are flattened again.  Uniting
     // everything at once instead makes single threads climb chains of hundreds of links: a run below a
     // tall shape that joins the background on its left to the background on its right.
+    // Round two only has something to do in a word where a run met a second run above, or went on meeting runs
+    // after its first word: round one notes those words (one bit per loop step; at most 32 steps at 512 x 512).
+    uint32_t again = 0u;
     auto contacts = [&](bool first_round) {
-        for (int wi = t + wc; wi < nw; wi += FX_BLOCK) {
+        int step = 0;
+        for (int wi = t + wc; wi < nw; wi += FX_BLOCK, step++) {
+            if (!first_round && !((again >> (step & 31)) & 1u))
+                continue;
+            int links = 0;
             const int y = sil_div(wi, dv), w = wi - y * wc;
             const uint32_t *row = m + y * wpr, *above = row - wpr;
             const uint32_t cur = row[w], u = above[w];
@@ -742,6 +768,7 @@ __device__ SilRuns sil_label(const uint32_t *m, int rows, int wc, SilDiv dv, int
                 if (first_round) {
                     // the first contact of a run in raster order: the lowest position claims the run
                     atomicMin(&R.val[a], b);
+                    links++;
                 } else if (R.val[a] != b) {
                     sil_unite(parent, a, b);
                 }
@@ -771,6 +798,10 @@ __device__ SilRuns sil_label(const uint32_t *m, int rows, int wc, SilDiv dv, int
                     link(pm + __popc(sm & sil_le(bit)) - 1u, sil_run_at(m, pre, y - 1, 32 * w + bit + 1, wc, wpr));
                 }
             }
+            // a single contact of a run that starts in this word is that run's first one (contacts further right, in
+            // this word or the next, meet runs with higher indices): nothing is left for round two
+            if (first_round && (links >= 2 || (links == 1 && (cur & 1u) && (mp >> 31))))
+                again |= 1u << (step & 31);
         }
     };
     auto flatten = [&]() {
@@ -878,8 +909,12 @@ __global__ __launch_bounds__(FX_BLOCK, 5) void sil_mask_kernel(SilArgs A)
     __shared__ double s_between[FX_WAVES_PER_BLOCK];
     __shared__ uint32_t s_hist[256];
     __shared__ uint32_t s_scan[16 + 256];
-    __shared__ uint16_t s_xtab[SIL_MAX_SIDE + 32], s_ytab[SIL_MAX_SIDE];
     __shared__ uint32_t s_runs[2 * SIL_RUNS_LDS];  // parent | per-root value of the labelling in progress
+    // the resize tables live in the run table's space: they are built after the contour stage's labelling has
+    // been read for the last time and read before the final labelling starts
+    static_assert((2 * SIL_MAX_SIDE + 32) * sizeof(uint16_t) <= sizeof(s_runs), "resize tables do not fit the run table");
+    uint16_t *const s_xtab = reinterpret_cast<uint16_t *>(s_runs);   // [SIL_MAX_SIDE + 32]
+    uint16_t *const s_ytab = s_xtab + SIL_MAX_SIDE + 32;              // [SIL_MAX_SIDE]
     __shared__ int s_v[SV_N];
     __shared__ unsigned long long s_best, s_first;
 #ifdef SIL_TIMING
@@ -900,7 +935,8 @@ __global__ __launch_bounds__(FX_BLOCK, 5) void sil_mask_kernel(SilArgs A)
     for (int64_t b = blockIdx.x; b < A.B; b += gridDim.x) {
         __syncthreads();
         // ---- Otsu level (reference :101-126): float64 in the reference's order
-        s_hist[t] = A.hist[b * 256 + t];
+        if (!CV)
+            s_hist[t] = A.hist[b * 256 + t];
         if (t < SV_N)
             s_v[t] = t == SV_MINX ? W : t == SV_MINY ? H : (t == SV_MAXX || t == SV_MAXY) ? -1 : 0;
         if (t == 0) {
@@ -1636,7 +1672,7 @@ extern "C" int fx_silhouette_batch_u8(const uint8_t *d_img, int64_t B, int H, in
         }
     }
     A.tr = tr;
-    const size_t blur_lds = mode == FX_SIL_OPENCV ? (size_t)(tr + 2 * SIL_CV_HALO) * Wp * 2 + 256 * sizeof(uint32_t)
+    const size_t blur_lds = mode == FX_SIL_OPENCV ? (size_t)(tr + 2 * SIL_CV_HALO) * Wp * 2 + (size_t)SIL_CV_HIST_COPIES * SIL_CV_HIST_PITCH * sizeof(uint32_t)
                                                   : (size_t)(tr + 2 * SIL_HALO) * Wp + 256 * sizeof(uint32_t);
     const size_t otsu_lds = (size_t)FX_WAVE * SIL_OTSU_PITCH * sizeof(uint32_t);
     if (mode == FX_SIL_OPENCV) {
