@@ -19,7 +19,25 @@ struct StreamState {
     std::mutex call_mu;  // held by an entry point from its first scratch request until it returns
     void *scratch[kScratchSlots] = {};
     size_t scratch_bytes[kScratchSlots] = {};
+    void *pin = nullptr;          // page-locked staging block for host-side arguments
+    size_t pin_bytes = 0;
+    hipEvent_t pin_ev = nullptr;  // recorded behind the copies out of `pin`
+    bool pin_busy = false;
 };
+
+void release_pin(StreamState &st)
+{
+    if (st.pin_busy && st.pin_ev)
+        (void)hipEventSynchronize(st.pin_ev);
+    st.pin_busy = false;
+    if (st.pin)
+        (void)hipHostFree(st.pin);
+    st.pin = nullptr;
+    st.pin_bytes = 0;
+    if (st.pin_ev)
+        (void)hipEventDestroy(st.pin_ev);
+    st.pin_ev = nullptr;
+}
 
 std::mutex g_mu;
 std::map<std::pair<int, hipStream_t>, std::unique_ptr<StreamState>> g_streams;
@@ -88,6 +106,48 @@ void *FxCallGuard::scratch(size_t bytes, int slot)
     return p;
 }
 
+void *FxCallGuard::staging(size_t bytes)
+{
+    if (!state) {
+        fx_set_error("fx staging: no current device");
+        return nullptr;
+    }
+    StreamState &st = *static_cast<StreamState *>(state);
+    if (st.pin_busy) {
+        const hipError_t e = hipEventSynchronize(st.pin_ev);
+        if (e != hipSuccess) {
+            fx_set_error("fx staging: hipEventSynchronize failed: %s", hipGetErrorString(e));
+            return nullptr;
+        }
+        st.pin_busy = false;
+    }
+    if (st.pin_bytes < bytes || !st.pin) {
+        if (st.pin)
+            (void)hipHostFree(st.pin);
+        st.pin = nullptr;
+        st.pin_bytes = 0;
+        const size_t want = bytes < (64u << 10) ? (64u << 10) : bytes;
+        const hipError_t e = hipHostMalloc(&st.pin, want, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            st.pin = nullptr;
+            fx_set_error("fx staging: hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+            return nullptr;
+        }
+        st.pin_bytes = want;
+    }
+    return st.pin;
+}
+
+int FxCallGuard::staged()
+{
+    StreamState &st = *static_cast<StreamState *>(state);
+    if (!st.pin_ev)
+        FX_HIP_CHECK(hipEventCreateWithFlags(&st.pin_ev, hipEventDisableTiming));
+    FX_HIP_CHECK(hipEventRecord(st.pin_ev, stream));
+    st.pin_busy = true;
+    return FX_OK;
+}
+
 FxProfileScope::FxProfileScope(hipStream_t s) : stream(s), active(g_profile)
 {
     if (!active)
@@ -143,6 +203,7 @@ int fx_shutdown(void)
         StreamState &st = *kv.second;
         std::lock_guard<std::mutex> call(st.call_mu);
         bool synced = false;
+        release_pin(st);
         for (int s = 0; s < kScratchSlots; s++) {
             if (!st.scratch[s])
                 continue;
@@ -166,6 +227,7 @@ int fx_release_stream(void *stream)
     if (!st)
         return FX_OK;
     std::lock_guard<std::mutex> call(st->call_mu);
+    release_pin(*st);
     for (int s = 0; s < kScratchSlots; s++) {
         if (st->scratch[s])
             FX_HIP_CHECK(hipFreeAsync(st->scratch[s], (hipStream_t)stream));

@@ -30,6 +30,13 @@ struct FxCallGuard {
     FxCallGuard &operator=(const FxCallGuard &) = delete;
     // NULL (and the error text set) on failure
     void *scratch(size_t bytes, int slot);
+    // Page-locked host block of the stream for small arguments the caller hands over in host memory
+    // (offset tables, work lists): the entry point fills it, enqueues its copies to the device from it and
+    // calls staged(); nothing waits for those copies.  The block is reused by the stream's next call, which
+    // first waits until the previous call's copies have left it (a wait for copies, not for kernels enqueued
+    // after them).  NULL (and the error text set) on failure.
+    void *staging(size_t bytes);
+    int staged();
 };
 
 // Defined beside the block it looks up (fx_hu.hip); fx_init calls it so that

@@ -10,6 +10,7 @@
 #include "fx_common.h"
 
 #include <algorithm>
+#include <string.h>
 #include <vector>
 
 namespace {
@@ -836,7 +837,16 @@ extern "C" int fx_center_scale(const void *d_pts, int wide, const int64_t *h_off
     A.out_centroid = d_centroid;
     A.out_maxdist = d_maxdist;
     A.total = total;
-    FX_HIP_CHECK(hipMemcpyAsync(base, h_offsets, (size_t)(B + 1) * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+    {
+        // the offsets go through the stream's page-locked block, so that nothing has to wait for the copy
+        void *pin = guard.staging((size_t)(B + 1) * sizeof(int64_t));
+        if (!pin)
+            return FX_ENOMEM;
+        memcpy(pin, h_offsets, (size_t)(B + 1) * sizeof(int64_t));
+        FX_HIP_CHECK(hipMemcpyAsync(base, pin, (size_t)(B + 1) * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+        if (guard.staged() != FX_OK)
+            return FX_EHIP;
+    }
     FxProfileScope prof(stream);
     FX_REQUIRE(B < (1ll << 31), "fx_center_scale: B = %lld", (long long)B);
     hipLaunchKernelGGL(cloud_colsum_kernel, dim3((unsigned)B), dim3(FX_BLOCK), 0, stream, A);
@@ -847,8 +857,6 @@ extern "C" int fx_center_scale(const void *d_pts, int wide, const int64_t *h_off
     hipLaunchKernelGGL(cloud_scale_kernel, dim3((unsigned)((span + FX_BLOCK - 1) / FX_BLOCK)), dim3(FX_BLOCK), 0,
                        stream, A);
     FX_HIP_CHECK(hipGetLastError());
-    // the staging copy of the offsets must not be overwritten by a later call before it has been read
-    FX_HIP_CHECK(hipStreamSynchronize(stream));
     return FX_OK;
 }
 
@@ -916,13 +924,23 @@ extern "C" int fx_fps_f32(const float *d_pts, const int64_t *h_offsets, int64_t 
     std::vector<int32_t> ids;
     for (int c = 0; c < 6; c++)
         ids.insert(ids.end(), cls[c].begin(), cls[c].end());
-    FX_HIP_CHECK(hipMemcpyAsync(base, h_offsets, (size_t)(B + 1) * sizeof(int64_t), hipMemcpyHostToDevice, stream));
-    FX_HIP_CHECK(hipMemcpyAsync(base + off_bytes, h_start, (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice, stream));
-    FX_HIP_CHECK(hipMemcpyAsync(base + off_bytes + start_bytes, ids.data(), (size_t)B * sizeof(int32_t),
-                                hipMemcpyHostToDevice, stream));
     unsigned char *big = base + off_bytes + start_bytes + ids_bytes;
-    if (!desc.empty())
-        FX_HIP_CHECK(hipMemcpyAsync(big, desc.data(), desc.size() * sizeof(FpsBigDesc), hipMemcpyHostToDevice, stream));
+    {
+        // offsets | start indices | cloud list | descriptors of the large clouds, laid out as in the scratch block,
+        // through the stream's page-locked block: one copy, and nothing waits for it
+        const size_t head = off_bytes + start_bytes + ids_bytes + desc_bytes;
+        unsigned char *pin = (unsigned char *)guard.staging(head);
+        if (!pin)
+            return FX_ENOMEM;
+        memcpy(pin, h_offsets, (size_t)(B + 1) * sizeof(int64_t));
+        memcpy(pin + off_bytes, h_start, (size_t)B * sizeof(int64_t));
+        memcpy(pin + off_bytes + start_bytes, ids.data(), (size_t)B * sizeof(int32_t));
+        if (!desc.empty())
+            memcpy(pin + off_bytes + start_bytes + ids_bytes, desc.data(), desc.size() * sizeof(FpsBigDesc));
+        FX_HIP_CHECK(hipMemcpyAsync(base, pin, head, hipMemcpyHostToDevice, stream));
+        if (guard.staged() != FX_OK)
+            return FX_EHIP;
+    }
     FpsArgs A;
     A.pts = d_pts;
     A.offsets = (const int64_t *)base;
@@ -967,7 +985,5 @@ extern "C" int fx_fps_f32(const float *d_pts, const int64_t *h_offsets, int64_t 
         }
     }
     FX_HIP_CHECK(hipGetLastError());
-    // the host vectors staged above go out of scope with this call
-    FX_HIP_CHECK(hipStreamSynchronize(stream));
     return FX_OK;
 }

@@ -234,7 +234,9 @@ int fx_gray_fit_batch_u8(const uint8_t *d_img, int64_t B, int H, int W,
  * Point-cloud normalisation and farthest point sampling, the stage that
  * produces the fixed-size sets fx_pca_batch_f32 reads.  B clouds stored back to
  * back, cloud b = rows h_offsets[b] .. h_offsets[b+1] (HOST array of B + 1
- * entries).  Both calls return after their work on `stream` has finished.
+ * entries).  The host arrays are copied through a page-locked block of the
+ * stream before the call returns, which it does without waiting for `stream`:
+ * the caller may reuse them at once, and outputs are valid in stream order.
  *
  * fx_center_scale replaces center_and_scale, src/preprocessing/prepare_all.py
  * :199-217: centroid = np.mean(points, axis=0) in float64 (rows added in

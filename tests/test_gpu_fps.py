@@ -137,6 +137,36 @@ def test_normalize_and_sample_pipeline(gpu, oracle):
         np.testing.assert_array_equal(got[k][1], cen)
 
 
+def test_host_arguments_may_be_reused_at_once(gpu, oracle):
+    """fx_center_scale / fx_fps_f32 do not wait for the stream: the host offset and start arrays are staged before
+    the call returns, so overwriting them right away (and calling again on the same stream) changes nothing."""
+    eng = pkg("engine")
+    rng = np.random.default_rng(3)
+    sizes = [3000, 20000, 700]
+    clouds = [cloud(rng, M) for M in sizes]
+    pts = torch.from_numpy(np.concatenate(clouds)).to(gpu)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    start = np.array([5, 17, 0], dtype=np.int64)
+    results = []
+    for rep in range(3):                              # back-to-back calls reuse the stream's staging block
+        o, s0 = off.copy(), start.copy()
+        cs = eng.center_scale(pts, o)
+        fp = eng.fps(cs["points"], o, 64, s0)
+        o[:] = 0
+        s0[:] = 0                                      # the caller's arrays change while the work is still queued
+        results.append((cs["points"], fp["idx"]))
+    torch.cuda.synchronize()
+    for norm_d, idx_d in results:
+        for k, c in enumerate(clouds):
+            norm = oracle.center_and_scale(c.astype(np.float64))[0]
+            np.testing.assert_array_equal(norm_d[off[k]:off[k + 1]].cpu().numpy(), norm)
+
+            class Fixed:
+                def randint(self, lo, hi, k=k):
+                    return int(start[k])
+            np.testing.assert_array_equal(idx_d[k].cpu().numpy(), oracle.farthest_point_sampling(norm, 64, Fixed()))
+
+
 def test_fps_rejects_bad_arguments(gpu):
     eng, lib = pkg("engine"), pkg("_lib")
     pts = torch.zeros((100, 3), dtype=torch.float32, device=gpu)
