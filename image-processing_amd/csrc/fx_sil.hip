@@ -878,7 +878,7 @@ __device__ __forceinline__ void sil_for_segments(const uint32_t *m, const uint32
 
 enum {
     SV_COUNT = 0, SV_THRESH, SV_INV, SV_MINX, SV_MINY, SV_MAXX, SV_MAXY, SV_CX0, SV_CY0, SV_CW, SV_CH, SV_NW,
-    SV_NH, SV_NRUNS, SV_ANYKEEP, SV_NEAR, SV_MAXSZ, SV_HOLES4, SV_N
+    SV_NH, SV_NRUNS, SV_ANYKEEP, SV_NEAR, SV_MAXSZ, SV_HOLES4, SV_REFILL, SV_N
 };
 
 // Block-wide bounding box: per-thread extremes into s_v[SV_MINX .. SV_MAXY].
@@ -1152,12 +1152,18 @@ __global__ __launch_bounds__(FX_BLOCK, 5) void sil_mask_kernel(SilArgs A)
                     atomicAdd(&s_v[SV_HOLES4], e4);
             }
             __syncthreads();
+            // First the mask is labelled as it is.  Without holes (as many components as the Euler number) its
+            // components are the external contours.  With holes the corner sums below give a component's outer area
+            // minus its holes' areas: the component with the largest such value is still the winner if it beats
+            // twice the bounding-box area of the box of every other component (an outer border cannot enclose more
+            // than its box), and its box is the same with or without the holes.  Only when that test fails are the
+            // holes filled (steps 1-3) and everything below is done again on the filled mask.
+            const auto contour_pass = [&](const uint32_t *mF, const bool first) -> bool {
             SilRuns fg;
-            fg.parent = fg.val = nullptr;
-            fg.n = 0;
-            bool filled = s_v[SV_HOLES4] <= 0;   // the hole-filling path is needed (or the mask is empty)
-            if (!filled) {
-                fg = sil_label(mA, H, wcH, GH.dv, wpr, true, pre, s_scan, &s_v[SV_NRUNS], s_runs, glob_runs, A.run_cap);
+            // (3) 8-connected components: of the mask as it is, or of the filled mask = the external contours
+            SIL_TICK(16);
+            fg = sil_label(mF, H, wcH, GH.dv, wpr, true, pre, s_scan, &s_v[SV_NRUNS], s_runs, glob_runs, A.run_cap);
+            if (first) {
                 int roots = 0;
                 for (int r = t; r < fg.n; r += FX_BLOCK)
                     roots += fg.parent[r] == (uint32_t)r ? 4 : 0;
@@ -1167,54 +1173,9 @@ __global__ __launch_bounds__(FX_BLOCK, 5) void sil_mask_kernel(SilArgs A)
                 if (fx_lane() == 0 && roots)
                     atomicSub(&s_v[SV_HOLES4], roots);   // 4 (E - C) = -4 holes
                 __syncthreads();
-                filled = s_v[SV_HOLES4] != 0;
             }
+            const bool holes = first && s_v[SV_HOLES4] != 0;
             SIL_TICK(15);
-            const uint32_t *mF = mA;   // the mask whose components are the external contours
-            if (filled) {
-            // (1) background runs, 4-connected; those that reach the image frame are the outside
-            for (int wi = t; wi < H * wcH; wi += FX_BLOCK) {
-                const int y = sil_div(wi, GH.dv), w = wi - y * wcH;
-                mB[y * wpr + w] = ~mA[y * wpr + w] & (w == wcH - 1 ? lastH : ~0u);
-            }
-            SilRuns bg = sil_label(mB, H, wcH, GH.dv, wpr, false, pre, s_scan, &s_v[SV_NRUNS], s_runs, glob_runs, A.run_cap);
-            for (int wi = t; wi < H * wcH; wi += FX_BLOCK) {
-                const int y = sil_div(wi, GH.dv), w = wi - y * wcH;
-                sil_for_segments(mB, pre, y, w, wcH, wpr, [&](uint32_t seg, uint32_t id) {
-                    const bool frame = y == 0 || y == H - 1 || (w == 0 && (seg & 1u)) ||
-                                       (w == wcH - 1 && ((seg >> ((W - 1) & 31)) & 1u));
-                    if (frame)
-                        bg.val[bg.parent[id]] = 1u;
-                });
-            }
-            __threadfence_block();
-            __syncthreads();
-            // (2) holes filled: components nested inside a hole vanish, outer borders stay as they are.  The
-            // complement is taken from mA again because mB is being overwritten.
-            for (int wi = t; wi < H * wcH; wi += FX_BLOCK) {
-                const int y = sil_div(wi, GH.dv), w = wi - y * wcH;
-                const uint32_t m = mA[y * wpr + w];
-                uint32_t comp = ~m & (w == wcH - 1 ? lastH : ~0u), holes = 0u;
-                if (comp) {
-                    const uint32_t cp = w > 0 ? ~mA[y * wpr + w - 1] : 0u;
-                    const uint32_t sm = comp & ~((comp << 1) | (cp >> 31));
-                    const uint32_t pm = pre[wi];
-                    while (comp) {
-                        const uint32_t low = comp & (0u - comp);
-                        const uint32_t seg = comp & ~(comp + low);
-                        const int bit = __ffs((int)comp) - 1;
-                        if (!bg.val[bg.parent[pm + __popc(sm & sil_le(bit)) - 1u]])
-                            holes |= seg;
-                        comp &= ~seg;
-                    }
-                }
-                mB[y * wpr + w] = m | holes;
-            }
-            // (3) 8-connected components of the filled mask = the external contours
-            SIL_TICK(16);
-            fg = sil_label(mB, H, wcH, GH.dv, wpr, true, pre, s_scan, &s_v[SV_NRUNS], s_runs, glob_runs, A.run_cap);
-            mF = mB;
-            }
             // (4) twice the signed area inside each outer border, as a sum over the corners of the pixel grid:
             // the border follower steps between the two foreground pixels of a straight corner and cuts across
             // the background pixel of a concave corner; saddle corners give two opposite steps that cancel.
@@ -1276,25 +1237,111 @@ __global__ __launch_bounds__(FX_BLOCK, 5) void sil_mask_kernel(SilArgs A)
                 }
             }
             __syncthreads();
-            int mnx = W, mny = H, mxx = -1, mxy = -1;
-            if (fg.n > 0) {
-                const uint32_t best = (uint32_t)(s_best & 0xFFFFFFFFull);
+            const uint32_t best = (uint32_t)(s_best & 0xFFFFFFFFull), best_a2 = (uint32_t)(s_best >> 32);
+            // boxes of all components at once (four words per run in the free mask buffer) when the winner has to be
+            // confirmed against the others' boxes; a scan for the winner's box alone otherwise
+            const bool all_boxes = holes && fg.n > 0 && 4 * fg.n <= nw;
+            bool again = holes && !all_boxes;
+            if (all_boxes) {
+                uint32_t *bx0 = mB, *bx1 = mB + fg.n, *by0 = mB + 2 * fg.n, *by1 = mB + 3 * fg.n;
+                for (int r = t; r < fg.n; r += FX_BLOCK) {
+                    bx0[r] = by0[r] = 0xFFFFFFFFu;
+                    bx1[r] = by1[r] = 0u;
+                }
+                __syncthreads();
                 for (int wi = t; wi < H * wcH; wi += FX_BLOCK) {
                     const int y = sil_div(wi, GH.dv), w = wi - y * wcH;
                     sil_for_segments(mF, pre, y, w, wcH, wpr, [&](uint32_t seg, uint32_t id) {
-                        if (fg.parent[id] != best)
-                            return;
-                        const int lo = 32 * w + __ffs((int)seg) - 1, hi = 32 * w + 31 - __clz((int)seg);
-                        mnx = lo < mnx ? lo : mnx;
-                        mxx = hi > mxx ? hi : mxx;
-                        mny = y < mny ? y : mny;
-                        mxy = y > mxy ? y : mxy;
+                        const uint32_t root = fg.parent[id];
+                        atomicMin(&bx0[root], (uint32_t)(32 * w + __ffs((int)seg) - 1));
+                        atomicMax(&bx1[root], (uint32_t)(32 * w + 31 - __clz((int)seg)));
+                        atomicMin(&by0[root], (uint32_t)y);
+                        atomicMax(&by1[root], (uint32_t)y);
                     });
                 }
+                __threadfence_block();
+                __syncthreads();
+                for (int r = t; r < fg.n; r += FX_BLOCK)
+                    if (fg.parent[r] == (uint32_t)r && (uint32_t)r != best &&
+                        2u * (bx1[r] - bx0[r]) * (by1[r] - by0[r]) >= best_a2)
+                        s_v[SV_REFILL] = 1;
+                __syncthreads();
+                again = s_v[SV_REFILL] != 0;
+                if (!again && t == 0) {
+                    s_v[SV_MINX] = (int)bx0[best];
+                    s_v[SV_MAXX] = (int)bx1[best];
+                    s_v[SV_MINY] = (int)by0[best];
+                    s_v[SV_MAXY] = (int)by1[best];
+                }
             }
-            sil_box_reduce(mnx, mny, mxx, mxy, s_v);
-            if (t == 0)
-                s_best = 0ull;
+            if (again) {   // block-uniform
+                __syncthreads();
+                if (t == 0)
+                    s_best = 0ull;
+                __syncthreads();
+                return true;
+            }
+            if (!all_boxes) {
+                int mnx = W, mny = H, mxx = -1, mxy = -1;
+                if (fg.n > 0) {
+                    for (int wi = t; wi < H * wcH; wi += FX_BLOCK) {
+                        const int y = sil_div(wi, GH.dv), w = wi - y * wcH;
+                        sil_for_segments(mF, pre, y, w, wcH, wpr, [&](uint32_t seg, uint32_t id) {
+                            if (fg.parent[id] != best)
+                                return;
+                            const int lo = 32 * w + __ffs((int)seg) - 1, hi = 32 * w + 31 - __clz((int)seg);
+                            mnx = lo < mnx ? lo : mnx;
+                            mxx = hi > mxx ? hi : mxx;
+                            mny = y < mny ? y : mny;
+                            mxy = y > mxy ? y : mxy;
+                        });
+                    }
+                }
+                sil_box_reduce(mnx, mny, mxx, mxy, s_v);
+            }
+            return false;
+            };
+            if (contour_pass(mA, true)) {
+            // (1) background runs, 4-connected; those that reach the image frame are the outside
+            for (int wi = t; wi < H * wcH; wi += FX_BLOCK) {
+                const int y = sil_div(wi, GH.dv), w = wi - y * wcH;
+                mB[y * wpr + w] = ~mA[y * wpr + w] & (w == wcH - 1 ? lastH : ~0u);
+            }
+            SilRuns bg = sil_label(mB, H, wcH, GH.dv, wpr, false, pre, s_scan, &s_v[SV_NRUNS], s_runs, glob_runs, A.run_cap);
+            for (int wi = t; wi < H * wcH; wi += FX_BLOCK) {
+                const int y = sil_div(wi, GH.dv), w = wi - y * wcH;
+                sil_for_segments(mB, pre, y, w, wcH, wpr, [&](uint32_t seg, uint32_t id) {
+                    const bool frame = y == 0 || y == H - 1 || (w == 0 && (seg & 1u)) ||
+                                       (w == wcH - 1 && ((seg >> ((W - 1) & 31)) & 1u));
+                    if (frame)
+                        bg.val[bg.parent[id]] = 1u;
+                });
+            }
+            __threadfence_block();
+            __syncthreads();
+            // (2) holes filled: components nested inside a hole vanish, outer borders stay as they are.  The
+            // complement is taken from mA again because mB is being overwritten.
+            for (int wi = t; wi < H * wcH; wi += FX_BLOCK) {
+                const int y = sil_div(wi, GH.dv), w = wi - y * wcH;
+                const uint32_t m = mA[y * wpr + w];
+                uint32_t comp = ~m & (w == wcH - 1 ? lastH : ~0u), holes = 0u;
+                if (comp) {
+                    const uint32_t cp = w > 0 ? ~mA[y * wpr + w - 1] : 0u;
+                    const uint32_t sm = comp & ~((comp << 1) | (cp >> 31));
+                    const uint32_t pm = pre[wi];
+                    while (comp) {
+                        const uint32_t low = comp & (0u - comp);
+                        const uint32_t seg = comp & ~(comp + low);
+                        const int bit = __ffs((int)comp) - 1;
+                        if (!bg.val[bg.parent[pm + __popc(sm & sil_le(bit)) - 1u]])
+                            holes |= seg;
+                        comp &= ~seg;
+                    }
+                }
+                mB[y * wpr + w] = m | holes;
+            }
+            (void)contour_pass(mB, false);
+            }
         }
         __syncthreads();
 
@@ -1600,8 +1647,8 @@ extern "C" int fx_silhouette_batch_u8(const uint8_t *d_img, int64_t B, int H, in
     }
 
     const int64_t px = (int64_t)H * W;
-    int64_t chunk = (int64_t)(1ll << 30) / px;
-    chunk = chunk < 1 ? 1 : (chunk > 32768 ? 32768 : chunk);
+    int64_t chunk = (int64_t)(1ll << 31) / px;   // blurred copies of a chunk: at most 2 GiB of scratch
+    chunk = chunk < 1 ? 1 : (chunk > 65536 ? 65536 : chunk);
     chunk = chunk > B ? B : chunk;
     const int rows = H > resolution ? H : resolution;
     const int side = W > resolution ? W : resolution;

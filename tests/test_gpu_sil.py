@@ -147,6 +147,22 @@ def test_degenerate_views(gpu, oracle, backend):
     nest[2, 80:110, 70:100] = 20
     check(gpu, oracle, nest, 128, 0.05, True)
     check(gpu, oracle, nest, 64, 0.0, True, min_size=5000)
+    # a thin ring around a solid square: the ring's pixels are fewer than the square's, but the ring is the only
+    # external contour (and the largest one); a second, separate square of the same size next to a ring; a ring
+    # whose hole holds another ring
+    thin = np.full((3, 160, 160), 240, dtype=np.uint8)
+    thin[0, 8:150, 8:150] = 20
+    thin[0, 16:142, 16:142] = 240
+    thin[0, 50:110, 50:110] = 20
+    thin[1, 5:75, 5:75] = 20
+    thin[1, 13:67, 13:67] = 240
+    thin[1, 90:150, 90:150] = 20
+    thin[2, 4:156, 4:156] = 20
+    thin[2, 12:148, 12:148] = 240
+    thin[2, 30:130, 30:130] = 20
+    thin[2, 40:120, 40:120] = 240
+    check(gpu, oracle, thin, 160, 0.05, True)
+    check(gpu, oracle, thin, 96, 0.0, True, min_size=1)
 
 
 def test_padded_rows_and_empty_batch(gpu, oracle, backend):
@@ -176,7 +192,7 @@ def test_large_batch_is_deterministic_and_chunked(gpu, oracle, backend):
     """More views than one internal chunk of blurred scratch holds at 512x512."""
     rng = np.random.default_rng(21)
     base = np.stack([gray_scene(rng, 512, 512, dark_object=bool(k & 1)) for k in range(8)])
-    reps = 640                                            # 5120 views x 256 KiB > 1 GiB
+    reps = 1100                                           # 8800 views x 256 KiB > 2 GiB
     d = torch.from_numpy(base).to(gpu).repeat(reps, 1, 1)
     eng = pkg("engine")
     out = eng.silhouette_batch(d, 224, 0.05, True, backend=backend)["mask"]
