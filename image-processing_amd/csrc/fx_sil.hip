@@ -607,7 +607,9 @@ __device__ __forceinline__ uint32_t sil_find(uint32_t *parent, uint32_t a)
 {
     volatile uint32_t *vp = parent;
     uint32_t p = vp[a];
-    while (p != a) {
+    // indices strictly decrease on the way up, so `a` steps are the most a sound table allows: the bound makes
+    // sure every wave leaves the loop whatever the table holds
+    for (uint32_t left = a; p != a && left; left--) {
         const uint32_t g = vp[p];
         if (g != p)
             atomicMin(&parent[a], g);
@@ -622,7 +624,7 @@ __device__ __forceinline__ uint32_t sil_find(uint32_t *parent, uint32_t a)
 // run above it) is one read and one atomic, without climbing.
 __device__ void sil_unite(uint32_t *parent, uint32_t a, uint32_t b)
 {
-    for (;;) {
+    for (int tries = 0; tries < 64; tries++) {   // a retry means another lane linked `a` first: a handful at most
         a = sil_find(parent, a);
         if (a == b)
             return;
@@ -806,7 +808,7 @@ __device__ SilRuns sil_label(const uint32_t *m, int rows, int wc, SilDiv dv, int
     };
     auto flatten = [&]() {
         // every run to its root: pointer jumping, the depth halves per round
-        for (;;) {
+        for (int round = 0; round < 48; round++) {   // the depth halves per round: 17 rounds flatten any chain of 2^17 runs
             int changed = 0;
             for (int r = t; r < R.n; r += FX_BLOCK) {
                 const uint32_t q = ((volatile uint32_t *)parent)[r];
