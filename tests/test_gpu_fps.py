@@ -101,10 +101,11 @@ def test_fps_large_clouds_structured(gpu, oracle):
 
 
 def test_fps_large_batch_mixed_sizes(gpu, oracle):
-    """One call with clouds of every size class, 100 000 and 300 000 points among them (groups of 256 points)."""
+    """One call with clouds of every size class, 100 000 and 300 000 points among them (groups of 256 points) and
+    one of 600 000 (64^3 grid, cell counters in global memory)."""
     eng = pkg("engine")
     rng = np.random.default_rng(31)
-    sizes = [100000, 900, 16385, 300000, 5000, 40000]
+    sizes = [100000, 900, 16385, 300000, 5000, 40000, 600000]
     clouds = [oracle.center_and_scale(cloud(rng, M).astype(np.float64))[0] for M in sizes]
     off = np.concatenate([[0], np.cumsum(sizes)])
     start = np.array([rng.integers(0, M) for M in sizes], dtype=np.int64)
