@@ -131,6 +131,20 @@ __device__ __forceinline__ float fx_wave_max_f32_dpp(float v)
     v = fmaxf(v, fx_dpp_f32<0x143, 0xc>(v));  // row_bcast:31 into rows 2 and 3
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+// Maximum of values that are >= 0 (or NaN, which wins): their bit patterns order like unsigned integers, and
+// an integer maximum folds into the DPP instruction (fmaxf needs a quieting step per operand).
+__device__ __forceinline__ float fx_wave_max_nonneg_f32_dpp(float f)
+{
+    uint32_t v = (uint32_t)__float_as_int(f);
+    const auto step = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+    v = step(v, (uint32_t)__float_as_int(fx_dpp_f32<0xB1, 0xf>(__int_as_float((int)v))));
+    v = step(v, (uint32_t)__float_as_int(fx_dpp_f32<0x4E, 0xf>(__int_as_float((int)v))));
+    v = step(v, (uint32_t)__float_as_int(fx_dpp_f32<0x141, 0xf>(__int_as_float((int)v))));
+    v = step(v, (uint32_t)__float_as_int(fx_dpp_f32<0x140, 0xf>(__int_as_float((int)v))));
+    v = step(v, (uint32_t)__float_as_int(fx_dpp_f32<0x142, 0xa>(__int_as_float((int)v))));
+    v = step(v, (uint32_t)__float_as_int(fx_dpp_f32<0x143, 0xc>(__int_as_float((int)v))));
+    return __int_as_float(__builtin_amdgcn_readlane((int)v, 63));
+}
 __device__ __forceinline__ float fx_wave_min_f32_dpp(float v)
 {
     v = fminf(v, fx_dpp_f32<0xB1, 0xf>(v));

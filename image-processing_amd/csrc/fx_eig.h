@@ -163,6 +163,101 @@ __device__ __forceinline__ void fx_eig3(double a00, double a01, double a02, doub
         v1[k] = (i0 == 0) ? V[k][0] : ((i0 == 1) ? V[k][1] : V[k][2]);
 }
 
+// Direct solve for well-conditioned matrices (three clearly separated,
+// clearly positive eigenvalues -- what a cloud of points in general position
+// gives), a few hundred instructions without a loop over sweeps:
+//   * the largest eigenvalue from the characteristic polynomial of the
+//     trace-free, scaled matrix B = (A - q I) / p: lambda1 = q + 2 p c with c the
+//     root of 4 c^3 - 3 c = det(B) / 2 in [1/2, 1] (c = cos(acos(.) / 3)), by
+//     Newton steps from 1/2 + sqrt((1 + r) / 2) / 2;
+//   * its eigenvector as the largest cross product of two rows of A - lambda1 I
+//     (error about eps * lambda1 / (lambda1 - lambda2));
+//   * the other two eigenvalues from the 2 x 2 matrix A induces on the plane
+//     orthogonal to that vector (closed form, the smaller one as product over
+//     the larger one: absolute error about eps * lambda1, where the roots of the
+//     cubic themselves lose half the digits when lambda2 and lambda3 are close),
+//     and lambda1 again as the Rayleigh quotient of the vector.
+// Returns false, with nothing usable in lam / v1, when the matrix is not of that
+// kind (lambda1 - lambda2 < 1e-3 lambda1, lambda3 < 1e-5 lambda1, a zero or
+// non-finite matrix): the caller then takes fx_eig3, whose sweeps keep exact
+// zeros and small eigenvalues to full relative accuracy.
+__device__ __forceinline__ bool fx_eig3_direct(double a00, double a01, double a02, double a11, double a12, double a22,
+                                               double (&lam)[3], double (&v1)[3])
+{
+    const double q = ((a00 + a11) + a22) * (1.0 / 3.0);
+    const double b00 = a00 - q, b11 = a11 - q, b22 = a22 - q;
+    const double p1 = fma(a01, a01, fma(a02, a02, a12 * a12));
+    const double p2 = fma(b00, b00, fma(b11, b11, fma(b22, b22, p1 + p1)));
+    if (!(p2 > 1e-290) || !(p2 < 1e290))
+        return false;
+    const double s6 = p2 * (1.0 / 6.0);
+    const double ip = fx_rsq_n1(s6);   // 1 / p
+    const double pp = s6 * ip;         // p
+    const double c00 = b00 * ip, c11 = b11 * ip, c22 = b22 * ip, c01 = a01 * ip, c02 = a02 * ip, c12 = a12 * ip;
+    double r = 0.5 * fma(c00, fma(c11, c22, -c12 * c12), fma(-c01, fma(c01, c22, -c12 * c02), c02 * fma(c01, c12, -c11 * c02)));
+    r = fmin(1.0, fmax(-1.0, r));
+    const double g = fma(0.5, r, 0.5);
+    double c = fma(0.5, g > 1e-300 ? g * fx_rsq_n1(g) : 0.0, 0.5);
+#pragma unroll
+    for (int it = 0; it < 5; it++) {
+        const double f = fma(fma(4.0 * c, c, -3.0), c, -r), fp = fma(12.0 * c, c, -3.0);
+        if (fp > 1e-30)
+            c = fma(-f, fx_rcp_n1(fp), c);
+    }
+    const double l1 = fma(pp + pp, c, q);
+    // rows of A - l1 I and their cross products
+    const double d0 = a00 - l1, d1 = a11 - l1, d2 = a22 - l1;
+    const double x0 = fma(a01, a12, -a02 * d1), y0 = fma(a02, a01, -d0 * a12), z0 = fma(d0, d1, -a01 * a01);    // r0 x r1
+    const double x1 = fma(a01, d2, -a02 * a12), y1 = fma(a02, a02, -d0 * d2), z1 = fma(d0, a12, -a01 * a02);    // r0 x r2
+    const double x2 = fma(d1, d2, -a12 * a12), y2 = fma(a12, a02, -a01 * d2), z2 = fma(a01, a12, -d1 * a02);    // r1 x r2
+    const double n0 = fma(x0, x0, fma(y0, y0, z0 * z0)), n1 = fma(x1, x1, fma(y1, y1, z1 * z1)),
+                 n2 = fma(x2, x2, fma(y2, y2, z2 * z2));
+    double vx = x0, vy = y0, vz = z0, nn = n0;
+    if (n1 > nn) {
+        vx = x1, vy = y1, vz = z1, nn = n1;
+    }
+    if (n2 > nn) {
+        vx = x2, vy = y2, vz = z2, nn = n2;
+    }
+    if (!(nn > 1e-290) || !(nn < 1e290))
+        return false;
+    const double in = fx_rsq_n1(nn);
+    vx *= in, vy *= in, vz *= in;
+    // an orthonormal pair (u, w) in the plane orthogonal to v: u = v x e for the axis e on which v is smallest
+    const double ax = fabs(vx), ay = fabs(vy), az = fabs(vz);
+    double ux, uy, uz;
+    if (ax <= ay && ax <= az) {
+        ux = 0.0, uy = vz, uz = -vy;
+    } else if (ay <= az) {
+        ux = -vz, uy = 0.0, uz = vx;
+    } else {
+        ux = vy, uy = -vx, uz = 0.0;
+    }
+    const double iu = fx_rsq_n1(fma(ux, ux, fma(uy, uy, uz * uz)));   // |u|^2 >= 2/3
+    ux *= iu, uy *= iu, uz *= iu;
+    const double wx = fma(vy, uz, -vz * uy), wy = fma(vz, ux, -vx * uz), wz = fma(vx, uy, -vy * ux);
+    const double Aux = fma(a00, ux, fma(a01, uy, a02 * uz)), Auy = fma(a01, ux, fma(a11, uy, a12 * uz)),
+                 Auz = fma(a02, ux, fma(a12, uy, a22 * uz));
+    const double Awx = fma(a00, wx, fma(a01, wy, a02 * wz)), Awy = fma(a01, wx, fma(a11, wy, a12 * wz)),
+                 Awz = fma(a02, wx, fma(a12, wy, a22 * wz));
+    const double Avx = fma(a00, vx, fma(a01, vy, a02 * vz)), Avy = fma(a01, vx, fma(a11, vy, a12 * vz)),
+                 Avz = fma(a02, vx, fma(a12, vy, a22 * vz));
+    const double m00 = fma(ux, Aux, fma(uy, Auy, uz * Auz)), m01 = fma(ux, Awx, fma(uy, Awy, uz * Awz)),
+                 m11 = fma(wx, Awx, fma(wy, Awy, wz * Awz));
+    const double l1r = fma(vx, Avx, fma(vy, Avy, vz * Avz));
+    const double h = 0.5 * (m00 - m11), mid = 0.5 * (m00 + m11);
+    const double rad2 = fma(h, h, m01 * m01);
+    const double l2 = mid + (rad2 > 1e-300 ? rad2 * fx_rsq_n1(rad2) : 0.0);
+    if (!(l2 > 0.0))
+        return false;
+    const double l3 = fma(m00, m11, -m01 * m01) * fx_rcp_n1(l2);
+    if (!(l1r - l2 >= 1e-3 * l1r) || !(l3 >= 1e-5 * l1r) || !(l1r < 1e300))
+        return false;
+    lam[0] = l1r, lam[1] = l2, lam[2] = l3;
+    v1[0] = vx, v1[1] = vy, v1[2] = vz;
+    return true;
+}
+
 // The nine scalars in front of the histogram (reference
 // src/features/extract_3d_pca_features.py:97-113,136-141): negative
 // eigenvalues clipped to 0, r_i = lambda_i / max(trace, 1e-12) (the reference

@@ -283,7 +283,9 @@ __global__ __launch_bounds__(FX_WAVE *WPB) void pca_sets_wave_kernel(PcaArgs A)
 // RED9_WORDS doubles of this wave.
 constexpr int RED9_PITCH = 65;  // rows one entry apart in the banks
 constexpr int RED9_WORDS = 9 * RED9_PITCH + 64 + 16;
-__device__ __forceinline__ void wave_sum9(double (&v)[9], double *slab)
+constexpr int RED9_TOT = 9 * RED9_PITCH + 64;   // the nine totals; seven spare doubles follow them
+// Leaves the totals in slab[RED9_TOT .. RED9_TOT + 8], visible to the wave.
+__device__ __forceinline__ void wave_sum9_slab(const double (&v)[9], double *slab)
 {
     const int lane = fx_lane();
 #pragma unroll
@@ -291,7 +293,7 @@ __device__ __forceinline__ void wave_sum9(double (&v)[9], double *slab)
         slab[k * RED9_PITCH + lane] = v[k];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    double *part = slab + 9 * RED9_PITCH, *tot = part + 64;
+    double *part = slab + 9 * RED9_PITCH, *tot = slab + RED9_TOT;
     if (lane < 63) {
         const int row = lane / 7, seg = lane - row * 7;
         const double *r = slab + row * RED9_PITCH + seg * 9;
@@ -315,9 +317,13 @@ __device__ __forceinline__ void wave_sum9(double (&v)[9], double *slab)
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void wave_sum9(double (&v)[9], double *slab)
+{
+    wave_sum9_slab(v, slab);
 #pragma unroll
     for (int k = 0; k < 9; k++)
-        v[k] = tot[k];
+        v[k] = slab[RED9_TOT + k];
 }
 
 #ifndef FX_PCA_NW
@@ -609,6 +615,16 @@ __global__ __launch_bounds__(FX_WAVE *NW, FX_PCA_WAVES) void pca_sets_redo_kerne
 // coordinates (v.x - v.mean); its error bound grows with the distance of the
 // set from the origin (sets far away send more points to the float64 path,
 // results are the same).
+// What the solving wave hands back for one set.
+struct SetRec {
+    double lam[3], v1[3];   // eigenvalues (descending, negative ones clipped to 0), first principal axis
+    double mean[3], rmax;   // rmax = 0: no scaling
+    float vq[4];            // float32 projection: vq[0..2] . x - vq[3]
+    float eps32;            // its error bound
+    int solved;
+    float head[9];
+    float pad;
+};
 template <int PPL, int NW, bool NORMALIZE>
 // (sets of 512 points leave room for a fifth wave per SIMD: 12 % faster there; at 1024 points it would spill)
 __global__ __launch_bounds__(FX_WAVE *NW, PPL <= 8 ? 5 : FX_PCA_WAVES) void pca_sets_full_kernel(PcaArgs A, double inv_n, double inv_nm1)
@@ -616,7 +632,8 @@ __global__ __launch_bounds__(FX_WAVE *NW, PPL <= 8 ? 5 : FX_PCA_WAVES) void pca_
     constexpr int HIST_COPIES = 8, HIST_PITCH = HIST_MAX + 1;
     __shared__ uint32_t hist_all[NW][HIST_COPIES * HIST_PITCH];
     __shared__ double red_all[NW][RED9_WORDS];
-    __shared__ double cov_all[NW][6], eig_all[NW][6];
+    __shared__ SetRec rec_all[NW];
+    static_assert(NW * 16 <= FX_WAVE, "a lane per (set, head scalar)");
     const int lane = fx_lane(), wave = fx_wave();
     constexpr int n = FX_WAVE * PPL;
     constexpr int G = PPL / 4;  // 4-point groups (48 bytes) per lane
@@ -664,110 +681,125 @@ __global__ __launch_bounds__(FX_WAVE *NW, PPL <= 8 ? 5 : FX_PCA_WAVES) void pca_
             v9[7] = fma(dy, dz, v9[7]);
             v9[8] = fma(dz, dz, v9[8]);
         }
-        wave_sum9(v9, red_all[wave]);
-        const double ox = v9[0] * inv_n, oy = v9[1] * inv_n, oz = v9[2] * inv_n;  // mean - pivot
-        const double mx = kx + ox, my = ky + oy, mz = kz + oz;
-        double S[6];
-        S[0] = fma(-v9[0], ox, v9[3]);
-        S[1] = fma(-v9[0], oy, v9[4]);
-        S[2] = fma(-v9[0], oz, v9[5]);
-        S[3] = fma(-v9[1], oy, v9[6]);
-        S[4] = fma(-v9[1], oz, v9[7]);
-        S[5] = fma(-v9[2], oz, v9[8]);
-        // every centred point lies within sqrt(sum of squared distances) of the mean
-        float reach32 = sqrtf((float)(S[0] + S[3] + S[5])) * 1.000001f;
-
-        // NORMALIZE is a template argument: as a run-time branch it makes the compiler keep all widened
-        // coordinates of the first pass alive for this one (48 more registers, one wave less per SIMD)
-        double rmax = 0.0;
+        // Everything that is computed once per set -- mean, covariance, eigen-solve, the nine scalars of the
+        // head, the float32 projection coefficients and their error bound -- is done by one wave of the block
+        // for all NW sets at once, a lane per set, instead of by every wave on 64 identical lanes (the duty
+        // rotates over the waves with the block index).  The sums go to it through the reduction slab, the
+        // results come back in a record per set.
+        double *slab = red_all[wave];
+        wave_sum9_slab(v9, slab);
         if (NORMALIZE) {
+            // NORMALIZE is a template argument: as a run-time branch it makes the compiler keep all widened
+            // coordinates of the first pass alive for this one (48 more registers, one wave less per SIMD)
+            const double mx = kx + slab[RED9_TOT] * inv_n, my = ky + slab[RED9_TOT + 1] * inv_n, mz = kz + slab[RED9_TOT + 2] * inv_n;
             double r2 = 0.0;
 #pragma unroll
             for (int i = 0; i < PPL; i++) {
                 const double dx = (double)x[i] - mx, dy = (double)y[i] - my, dz = (double)z[i] - mz;
                 r2 = fmax(r2, dx * dx + dy * dy + dz * dz);
             }
-            rmax = sqrt(fx_wave_max_f64_dpp(r2));
+            const double rmax = sqrt(fx_wave_max_f64_dpp(r2));
+            if (lane == 0)
+                slab[RED9_TOT + 9] = rmax;
         }
-        const bool scale = NORMALIZE && rmax > 0.0;
-        if (scale) {
-            const double w = 1.0 / (rmax * rmax);
+        if (lane == 0) {
+            slab[RED9_TOT + 10] = kx;
+            slab[RED9_TOT + 11] = ky;
+            slab[RED9_TOT + 12] = kz;
+        }
+        __syncthreads();
+        if (wave == (int)(blockIdx.x % NW)) {
+            if (lane < NW) {
+                const double *t = red_all[lane] + RED9_TOT;
+                SetRec *rec = &rec_all[lane];
+                const double ox = t[0] * inv_n, oy = t[1] * inv_n, oz = t[2] * inv_n;  // mean - pivot
+                const double mx = t[10] + ox, my = t[11] + oy, mz = t[12] + oz;
+                double S[6];
+                S[0] = fma(-t[0], ox, t[3]);
+                S[1] = fma(-t[0], oy, t[4]);
+                S[2] = fma(-t[0], oz, t[5]);
+                S[3] = fma(-t[1], oy, t[6]);
+                S[4] = fma(-t[1], oz, t[7]);
+                S[5] = fma(-t[2], oz, t[8]);
+                // every centred point lies within sqrt(sum of squared distances) of the mean
+                const float reach32 = sqrtf((float)(S[0] + S[3] + S[5])) * 1.000001f;
+                const double rmax = NORMALIZE ? t[9] : 0.0;
+                const bool scale = NORMALIZE && rmax > 0.0;
+                double wcov = inv_nm1;  // np.cov multiplies by 1/(n-1)
+                if (scale)
+                    wcov *= 1.0 / (rmax * rmax);
+                double lam[3] = {0.0, 0.0, 0.0}, v1[3] = {0.0, 0.0, 0.0};
+                // Matrices the direct solve does not take (eigenvalues too close, or one next to nothing) go
+                // to pca_sets_redo_kernel with the set.
+                const bool solved = fx_eig3_direct(S[0] * wcov, S[1] * wcov, S[2] * wcov, S[3] * wcov, S[4] * wcov, S[5] * wcov, lam, v1);
 #pragma unroll
-            for (int k = 0; k < 6; k++)
-                S[k] *= w;
-        }
-
-        // eigen-solve: one wave of the block, a lane per set (see pca_sets_reg_kernel)
-        double lam[3], v1[3];
-        {
-            if (lane < 6) {
-                double c = S[0];
-                c = lane == 1 ? S[1] : c;
-                c = lane == 2 ? S[2] : c;
-                c = lane == 3 ? S[3] : c;
-                c = lane == 4 ? S[4] : c;
-                c = lane == 5 ? S[5] : c;
-                cov_all[wave][lane] = c * inv_nm1;  // np.cov multiplies by 1/(n-1)
+                for (int q = 0; q < 3; q++) {
+                    rec->lam[q] = lam[q] < 0.0 ? 0.0 : lam[q];
+                    rec->v1[q] = v1[q];
+                }
+                rec->mean[0] = mx, rec->mean[1] = my, rec->mean[2] = mz;
+                rec->rmax = scale ? rmax : 0.0;
+                // float32 value of a projection: v.x - v.mean in three FMAs.  Each of its five roundings is
+                // relative to a partial sum of at most |v.mean| + |v| |x| <= w (|mean|_1 + |mean|_2 + reach):
+                // eps32 bounds the total generously.  It settles every point that is not within eps32 of a
+                // decision; those few are decided in float64.
+                const float w32 = scale ? (float)(1.0 / rmax) : 1.0f;
+                rec->vq[0] = (float)v1[0] * w32;
+                rec->vq[1] = (float)v1[1] * w32;
+                rec->vq[2] = (float)v1[2] * w32;
+                rec->vq[3] = (float)(fma(v1[2], mz, fma(v1[1], my, v1[0] * mx))) * w32;
+                const float m1 = fabsf((float)mx) + fabsf((float)my) + fabsf((float)mz);
+                rec->eps32 = 1e-6f * w32 * (2.0f * m1 + reach32) + 1e-37f;
+                rec->solved = solved ? 1 : 0;
             }
-            __syncthreads();
-            if (wave == (int)(blockIdx.x % NW) && lane < NW) {
-                const double *c = cov_all[lane];
-                double l3[3], w3[3];
-                fx_eig3<true>(c[0], c[1], c[2], c[3], c[4], c[5], l3, w3);
-                double *e = eig_all[lane];
-                e[0] = l3[0], e[1] = l3[1], e[2] = l3[2];
-                e[3] = w3[0], e[4] = w3[1], e[5] = w3[2];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // the nine scalars of the head, a lane per (set, scalar): one division for the whole block
+            const int hs = lane >> 4, e = lane & 15;
+            if (hs < NW && e < 9) {
+                const double *lam = rec_all[hs].lam;
+                const double trace = lam[0] + lam[1] + lam[2];
+                const double safe = trace > 1e-12 ? trace : 1e-12;
+                const double num = (e == 0 || e == 3 || e == 6) ? lam[0] : (e == 1 || e == 4 || e == 7) ? lam[1] : (e == 2 || e == 5) ? lam[2] : trace;
+                const double den = e < 3 || e == 8 ? 1.0 : e < 6 ? safe : e == 6 ? lam[1] + 1e-12 : lam[2] + 1e-12;
+                rec_all[hs].head[e] = (float)(num / den);
             }
-            __syncthreads();
-            const double *e = eig_all[wave];
-            lam[0] = e[0], lam[1] = e[1], lam[2] = e[2];
-            v1[0] = e[3], v1[1] = e[4], v1[2] = e[5];
         }
-#pragma unroll
-        for (int q = 0; q < 3; q++)
-            lam[q] = lam[q] < 0.0 ? 0.0 : lam[q];
-        const double trace = lam[0] + lam[1] + lam[2];
-        double head_mine;
-        {
-            const double safe = trace > 1e-12 ? trace : 1e-12;
-            const int e = lane < 9 ? lane : 0;
-            const double num = (e == 0 || e == 3 || e == 6) ? lam[0] : (e == 1 || e == 4 || e == 7) ? lam[1] : (e == 2 || e == 5) ? lam[2] : trace;
-            const double den = e < 3 || e == 8 ? 1.0 : e < 6 ? safe : e == 6 ? lam[1] + 1e-12 : lam[2] + 1e-12;
-            head_mine = num / den;
+        __syncthreads();
+        const SetRec *rec = &rec_all[wave];
+        if (!rec->solved) {   // wave-uniform; after the block's last barrier
+            if (live && lane == 0)
+                A.redo_list[atomicAdd(A.redo_count, 1)] = (int32_t)set;
+            return;
         }
+        const bool scale = NORMALIZE && rec->rmax > 0.0;
 
         // float64 value of a point (the formula of record)
         auto proj = [&](float px, float py, float pz) -> double {
-            double dx = (double)px - mx, dy = (double)py - my, dz = (double)pz - mz;
+            double dx = (double)px - rec->mean[0], dy = (double)py - rec->mean[1], dz = (double)pz - rec->mean[2];
             if (scale) {
+                const double rmax = rec->rmax;
                 dx /= rmax;
                 dy /= rmax;
                 dz /= rmax;
             }
-            return fabs(fma(dz, v1[2], fma(dy, v1[1], dx * v1[0])));
+            return fabs(fma(dz, rec->v1[2], fma(dy, rec->v1[1], dx * rec->v1[0])));
         };
-        // float32 value: v.x - v.mean in three FMAs.  Each of its five roundings is relative to a partial sum
-        // of at most |v.mean| + |v| |x| <= w (|mean|_1 + |mean|_2 + reach): eps32 bounds the total generously.
-        // It settles every point that is not within eps32 of a decision; those few are decided in float64.
-        const float w32 = scale ? (float)(1.0 / rmax) : 1.0f;
-        const float vx32 = (float)v1[0] * w32, vy32 = (float)v1[1] * w32, vz32 = (float)v1[2] * w32;
-        const float c32 = (float)(fma(v1[2], mz, fma(v1[1], my, v1[0] * mx))) * w32;
-        const float m1 = fabsf((float)mx) + fabsf((float)my) + fabsf((float)mz);
-        const float eps32 = 1e-6f * w32 * (2.0f * m1 + reach32) + 1e-37f;
+        const float vx32 = rec->vq[0], vy32 = rec->vq[1], vz32 = rec->vq[2], c32 = rec->vq[3], eps32 = rec->eps32;
         float top32 = 0.0f;
 #pragma unroll
         for (int i = 0; i < PPL; i++)
             top32 = fmaxf(top32, fabsf(fmaf(z[i], vz32, fmaf(y[i], vy32, fmaf(x[i], vx32, -c32)))));
-        top32 = fx_wave_max_f32_dpp(top32);
+        top32 = fx_wave_max_nonneg_f32_dpp(top32);
         // Points that float32 cannot settle are appended to a short list in LDS (a wave-uniform branch per point
         // index, taken for about one index in sixteen) and evaluated in float64 afterwards, a lane per listed
         // point: the float64 code exists once and runs without divergence.
         float *slow_list = reinterpret_cast<float *>(red_all[wave]);  // the reduction slab is free again
         constexpr int SLOW_CAP = (RED9_WORDS * 2) / 3 - FX_WAVE;  // points the slab holds, one wave's worth in reserve
         int n_slow = 0;
-        auto append = [&](unsigned long long mask, float px, float py, float pz) {
+        auto append = [&](unsigned long long mask, bool mine, float px, float py, float pz) {
             const int pos = n_slow + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            if ((mask >> lane) & 1ull) {
+            if (mine) {
                 slow_list[3 * pos] = px;
                 slow_list[3 * pos + 1] = py;
                 slow_list[3 * pos + 2] = pz;
@@ -786,21 +818,24 @@ __global__ __launch_bounds__(FX_WAVE *NW, PPL <= 8 ? 5 : FX_PCA_WAVES) void pca_
         // listed points, and they are binned with it in float64.
         bool redo = !(top32 > 8.0f * eps32);   // projections at rounding level: everything in float64, below
         double top = 0.0;
+        const float inv32 = (float)nb / top32;
+        const float qx = vx32 * inv32, qy = vy32 * inv32, qz = vz32 * inv32, qc = c32 * inv32;
+        auto q32 = [&](float px, float py, float pz) -> float { return fabsf(fmaf(pz, qz, fmaf(py, qy, fmaf(px, qx, -qc)))); };
         if (!redo) {
-            const float inv32 = (float)nb / top32;
-            const float qx = vx32 * inv32, qy = vy32 * inv32, qz = vz32 * inv32, qc = c32 * inv32;
             const float margin = (3.0f * eps32 + 6e-7f * top32) * inv32 + 1e-5f * (float)nb;
 #pragma unroll
             for (int i = 0; i < PPL; i++) {
-                const float q = fabsf(fmaf(z[i], qz, fmaf(y[i], qy, fmaf(x[i], qx, -qc))));
+                // every point is counted in the bin float32 gives it (q <= n_bins + margin: the row has a spare
+                // entry); a listed point is taken out of that bin again when the list is evaluated
+                const float q = q32(x[i], y[i], z[i]);
                 const bool slow = fabsf(q - rintf(q)) < margin;
-                atomicAdd(&my_hist[slow ? HIST_MAX : (int)q], 1u);
+                atomicAdd(&my_hist[(int)q], 1u);
                 const unsigned long long mask = __builtin_amdgcn_ballot_w64(slow);
                 if (mask && !redo) {
                     if (n_slow > SLOW_CAP)
                         redo = true;   // degenerate sets (most points at one |projection|): the list would overflow
                     else
-                        append(mask, x[i], y[i], z[i]);
+                        append(mask, slow, x[i], y[i], z[i]);
                 }
             }
         }
@@ -818,9 +853,11 @@ __global__ __launch_bounds__(FX_WAVE *NW, PPL <= 8 ? 5 : FX_PCA_WAVES) void pca_
         {
             const double step = top / (double)nb;
             const double inv_step = (double)nb / top;
-            for (int e = lane; e < n_slow; e += FX_WAVE)
-                atomicAdd(&my_hist[fx_hist_bin(proj(slow_list[3 * e], slow_list[3 * e + 1], slow_list[3 * e + 2]), step,
-                                               inv_step, nb)], 1u);
+            for (int e = lane; e < n_slow; e += FX_WAVE) {
+                const float px = slow_list[3 * e], py = slow_list[3 * e + 1], pz = slow_list[3 * e + 2];
+                atomicSub(&my_hist[(int)q32(px, py, pz)], 1u);   // the same arithmetic as in the pass: the same bin
+                atomicAdd(&my_hist[fx_hist_bin(proj(px, py, pz), step, inv_step, nb)], 1u);
+            }
         }
         list_sync();
         if (live && lane < nb) {
@@ -831,16 +868,9 @@ __global__ __launch_bounds__(FX_WAVE *NW, PPL <= 8 ? 5 : FX_PCA_WAVES) void pca_
             A.out[set * width + 9 + lane] = (float)h / (float)n;
         }
         if (live && lane < 9)
-            A.out[set * width + lane] = (float)head_mine;
-        if (live && A.eig && lane < 6) {
-            double e = lam[0];
-            e = lane == 1 ? lam[1] : e;
-            e = lane == 2 ? lam[2] : e;
-            e = lane == 3 ? v1[0] : e;
-            e = lane == 4 ? v1[1] : e;
-            e = lane == 5 ? v1[2] : e;
-            A.eig[set * 6 + lane] = e;
-        }
+            A.out[set * width + lane] = rec->head[lane];
+        if (live && A.eig && lane < 6)
+            A.eig[set * 6 + lane] = rec->lam[lane];   // lam[3] and v1[3] lie one after the other
     }
 }
 
