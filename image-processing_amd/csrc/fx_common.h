@@ -131,20 +131,6 @@ __device__ __forceinline__ float fx_wave_max_f32_dpp(float v)
     v = fmaxf(v, fx_dpp_f32<0x143, 0xc>(v));  // row_bcast:31 into rows 2 and 3
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
-// Maximum of values that are >= 0 (or NaN, which wins): their bit patterns order like unsigned integers, and
-// an integer maximum folds into the DPP instruction (fmaxf needs a quieting step per operand).
-__device__ __forceinline__ float fx_wave_max_nonneg_f32_dpp(float f)
-{
-    uint32_t v = (uint32_t)__float_as_int(f);
-    const auto step = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
-    v = step(v, (uint32_t)__float_as_int(fx_dpp_f32<0xB1, 0xf>(__int_as_float((int)v))));
-    v = step(v, (uint32_t)__float_as_int(fx_dpp_f32<0x4E, 0xf>(__int_as_float((int)v))));
-    v = step(v, (uint32_t)__float_as_int(fx_dpp_f32<0x141, 0xf>(__int_as_float((int)v))));
-    v = step(v, (uint32_t)__float_as_int(fx_dpp_f32<0x140, 0xf>(__int_as_float((int)v))));
-    v = step(v, (uint32_t)__float_as_int(fx_dpp_f32<0x142, 0xa>(__int_as_float((int)v))));
-    v = step(v, (uint32_t)__float_as_int(fx_dpp_f32<0x143, 0xc>(__int_as_float((int)v))));
-    return __int_as_float(__builtin_amdgcn_readlane((int)v, 63));
-}
 __device__ __forceinline__ float fx_wave_min_f32_dpp(float v)
 {
     v = fminf(v, fx_dpp_f32<0xB1, 0xf>(v));
@@ -166,6 +152,33 @@ __device__ __forceinline__ double fx_wave_max_f64_dpp(double v)
     const long long b = __double_as_longlong(v);
     const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)b, 63);
     const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// Wave-wide maximum of unsigned integers.  The lanes a DPP step does not write take 0, the identity of the
+// maximum, so move and maximum fold into one DPP instruction per step.
+__device__ __forceinline__ uint32_t fx_wave_max_u32_dpp(uint32_t v)
+{
+    const auto step = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+    v = step(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false));
+    v = step(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false));
+    v = step(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false));
+    v = step(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, false));
+    v = step(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
+    v = step(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// Maximum of floats / doubles that are >= 0 (or NaN, which wins): their bit patterns order like unsigned
+// integers.  For doubles the high words first, then the low words of the lanes that hold the maximal high word.
+__device__ __forceinline__ float fx_wave_max_nonneg_f32_dpp(float f)
+{
+    return __int_as_float((int)fx_wave_max_u32_dpp((uint32_t)__float_as_int(f)));
+}
+__device__ __forceinline__ double fx_wave_max_nonneg_f64_dpp(double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const uint32_t hi = fx_wave_max_u32_dpp((uint32_t)(b >> 32));
+    const uint32_t lo = fx_wave_max_u32_dpp((uint32_t)(b >> 32) == hi ? (uint32_t)b : 0u);
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 

@@ -298,4 +298,16 @@ __device__ __forceinline__ int fx_hist_bin(double v, double step, double inv_ste
     return k;
 }
 
+// The same bin from a first guess that is at most one off (v * inv_step with inv_step within 1e-6 of
+// n_bins / top): one step down or up instead of the loops.
+__device__ __forceinline__ int fx_hist_bin_near(double v, double step, double inv_step, int n_bins)
+{
+    int k = (int)(v * inv_step);
+    k = k > n_bins - 1 ? n_bins - 1 : k;
+    k = k < 0 ? 0 : k;
+    const bool down = k > 0 && v < (double)k * step;
+    const bool up = k < n_bins - 1 && v >= (double)(k + 1) * step;
+    return down ? k - 1 : up ? k + 1 : k;
+}
+
 #endif  // __HIPCC__

@@ -627,7 +627,7 @@ struct SetRec {
 };
 template <int PPL, int NW, bool NORMALIZE>
 // (sets of 512 points leave room for a fifth wave per SIMD: 12 % faster there; at 1024 points it would spill)
-__global__ __launch_bounds__(FX_WAVE *NW, PPL <= 8 ? 5 : FX_PCA_WAVES) void pca_sets_full_kernel(PcaArgs A, double inv_n, double inv_nm1)
+__global__ __launch_bounds__(FX_WAVE *NW, PPL <= 8 ? 5 : FX_PCA_WAVES) void pca_sets_full_kernel(PcaArgs A, double inv_n, double inv_nm1, double inv_nb)
 {
     constexpr int HIST_COPIES = 8, HIST_PITCH = HIST_MAX + 1;
     __shared__ uint32_t hist_all[NW][HIST_COPIES * HIST_PITCH];
@@ -847,16 +847,30 @@ __global__ __launch_bounds__(FX_WAVE *NW, PPL <= 8 ? 5 : FX_PCA_WAVES) void pca_
             return;   // after the block's last barrier
         }
         list_sync();
-        for (int e = lane; e < n_slow; e += FX_WAVE)
+        // (a list of up to 64 points, the usual case, is one point per lane: its value is kept for the binning)
+        const double mine = lane < n_slow ? proj(slow_list[3 * lane], slow_list[3 * lane + 1], slow_list[3 * lane + 2]) : 0.0;
+        top = mine;
+        for (int e = lane + FX_WAVE; e < n_slow; e += FX_WAVE)
             top = fmax(top, proj(slow_list[3 * e], slow_list[3 * e + 1], slow_list[3 * e + 2]));
-        top = fx_wave_max_f64_dpp(top);
+        top = fx_wave_max_nonneg_f64_dpp(top);
+        if (!(top > 1e-280) || !(top < 1e280)) {   // the shortcuts below assume a plain double
+            if (live && lane == 0)
+                A.redo_list[atomicAdd(A.redo_count, 1)] = (int32_t)set;
+            return;
+        }
         {
-            const double step = top / (double)nb;
-            const double inv_step = (double)nb / top;
+            // step = top / n_bins, correctly rounded, from the host's correctly rounded 1 / n_bins: two
+            // residual corrections (the first makes the quotient faithful, the second then rounds it
+            // correctly -- Markstein's theorem)
+            const double dnb = (double)nb;
+            double step = top * inv_nb;
+            step = fma(fma(-dnb, step, top), inv_nb, step);
+            step = fma(fma(-dnb, step, top), inv_nb, step);
+            const double inv_step = dnb * __builtin_amdgcn_rcp(top);   // within 1e-7: fx_hist_bin_near corrects the bin
             for (int e = lane; e < n_slow; e += FX_WAVE) {
                 const float px = slow_list[3 * e], py = slow_list[3 * e + 1], pz = slow_list[3 * e + 2];
                 atomicSub(&my_hist[(int)q32(px, py, pz)], 1u);   // the same arithmetic as in the pass: the same bin
-                atomicAdd(&my_hist[fx_hist_bin(proj(px, py, pz), step, inv_step, nb)], 1u);
+                atomicAdd(&my_hist[fx_hist_bin_near(e == lane ? mine : proj(px, py, pz), step, inv_step, nb)], 1u);
             }
         }
         list_sync();
@@ -1246,7 +1260,8 @@ int launch_full_sets(const PcaArgs &A, hipStream_t s)
     const int64_t n = (int64_t)FX_WAVE * PPL;
     FX_REQUIRE(A.redo_list && A.redo_count, "fx_pca_batch_f32: no list for the sets to redo");
     FX_HIP_CHECK(hipMemsetAsync(A.redo_count, 0, sizeof(int32_t), s));
-    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(FX_WAVE * NW), 0, s, A, 1.0 / (double)n, 1.0 / (double)(n - 1));
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(FX_WAVE * NW), 0, s, A, 1.0 / (double)n, 1.0 / (double)(n - 1),
+                       1.0 / (double)A.n_bins);
     PcaArgs R = A;
     R.set_ids = A.redo_list;
     R.n_sets_dev = A.redo_count;
