@@ -473,7 +473,9 @@ __device__ __forceinline__ void pca_sets_reg_body(const PcaArgs &A, const int64_
         if (wave == (int)(blk % NW) && lane < NW) {
             const double *c = cov_all[lane];
             double l3[3], w3[3];
-            fx_eig3<true>(c[0], c[1], c[2], c[3], c[4], c[5], l3, w3);
+            // the direct solve where it applies (well separated, clearly positive eigenvalues), the sweeps otherwise
+            if (!fx_eig3_direct(c[0], c[1], c[2], c[3], c[4], c[5], l3, w3))
+                fx_eig3<true>(c[0], c[1], c[2], c[3], c[4], c[5], l3, w3);
             double *e = eig_all[lane];
             e[0] = l3[0], e[1] = l3[1], e[2] = l3[2];
             e[3] = w3[0], e[4] = w3[1], e[5] = w3[2];
