@@ -584,7 +584,8 @@ __device__ __forceinline__ void pca_sets_reg_body(const PcaArgs &A, const int64_
 }
 
 template <int PPL, bool RAGGED, int NW>
-__global__ __launch_bounds__(FX_WAVE *NW, FX_PCA_WAVES) void pca_sets_reg_kernel(PcaArgs A)
+// (32 points per lane, sets of 1025..2048 points: 96 registers of coordinates, two waves per SIMD)
+__global__ __launch_bounds__(FX_WAVE *NW, PPL > 16 ? 2 : FX_PCA_WAVES) void pca_sets_reg_kernel(PcaArgs A)
 {
     const int64_t n_sets = A.n_sets_dev ? (int64_t)*A.n_sets_dev : A.n_sets;
     if ((int64_t)blockIdx.x * NW >= n_sets)
@@ -1307,6 +1308,15 @@ int launch_reg_sets(const PcaArgs &A, int64_t max_points, bool ragged, hipStream
 
 int launch_small_sets(const PcaArgs &A, int64_t max_points, hipStream_t s)
 {
+    if (A.dims == 3 && max_points > REG_SET_MAX_POINTS && max_points <= 2 * REG_SET_MAX_POINTS) {
+        // 3-D sets of 1025..2048 points: the register kernel with 32 points per lane
+        constexpr int NW = FX_PCA_NW;
+        const int64_t blocks = (A.n_sets + NW - 1) / NW;
+        FX_REQUIRE(blocks <= 0x7fffffffLL, "fx_pca_batch_f32: too many sets for one launch");
+        hipLaunchKernelGGL((pca_sets_reg_kernel<32, true, NW>), dim3((unsigned)blocks), dim3(FX_WAVE * NW), 0, s, A);
+        FX_HIP_CHECK(hipGetLastError());
+        return FX_OK;
+    }
     // keep each block's LDS near 48 KiB so that three blocks share a CU
     if (max_points <= 1024)
         return launch_wave_kernel<4>(A, max_points, s);
