@@ -880,7 +880,7 @@ __device__ __forceinline__ void sil_for_segments(const uint32_t *m, const uint32
 
 enum {
     SV_COUNT = 0, SV_THRESH, SV_INV, SV_MINX, SV_MINY, SV_MAXX, SV_MAXY, SV_CX0, SV_CY0, SV_CW, SV_CH, SV_NW,
-    SV_NH, SV_NRUNS, SV_ANYKEEP, SV_NEAR, SV_MAXSZ, SV_HOLES4, SV_REFILL, SV_N
+    SV_NH, SV_NRUNS, SV_ANYKEEP, SV_NEAR, SV_MAXSZ, SV_HOLES4, SV_REFILL, SV_NROOT_FG, SV_NROOT_CC, SV_N
 };
 
 // Block-wide bounding box: per-thread extremes into s_v[SV_MINX .. SV_MAXY].
@@ -1172,9 +1172,29 @@ __global__ __launch_bounds__(FX_BLOCK, 5) void sil_mask_kernel(SilArgs A)
 #pragma unroll
                 for (int o = FX_WAVE / 2; o > 0; o >>= 1)
                     roots += __shfl_xor(roots, o, FX_WAVE);
-                if (fx_lane() == 0 && roots)
+                if (fx_lane() == 0 && roots) {
                     atomicSub(&s_v[SV_HOLES4], roots);   // 4 (E - C) = -4 holes
+                    atomicAdd(&s_v[SV_NROOT_FG], roots >> 2);
+                }
                 __syncthreads();
+                // A single component (the usual silhouette) is the winner whatever its area and holes: its box is
+                // the box of the foreground.
+                if (s_v[SV_NROOT_FG] == 1) {   // block-uniform
+                    int mnx = W, mny = H, mxx = -1, mxy = -1;
+                    for (int wi = t; wi < H * wcH; wi += FX_BLOCK) {
+                        const int y = sil_div(wi, GH.dv), w = wi - y * wcH;
+                        const uint32_t m = mF[y * wpr + w];
+                        if (m) {
+                            const int lo = 32 * w + __ffs((int)m) - 1, hi = 32 * w + 31 - __clz((int)m);
+                            mnx = lo < mnx ? lo : mnx;
+                            mxx = hi > mxx ? hi : mxx;
+                            mny = y < mny ? y : mny;
+                            mxy = y > mxy ? y : mxy;
+                        }
+                    }
+                    sil_box_reduce(mnx, mny, mxx, mxy, s_v);
+                    return false;
+                }
             }
             const bool holes = first && s_v[SV_HOLES4] != 0;
             SIL_TICK(15);
@@ -1508,6 +1528,22 @@ __global__ __launch_bounds__(FX_BLOCK, 5) void sil_mask_kernel(SilArgs A)
         const int nwS = new_h * wcS;
         SilRuns cc = sil_label(mB, new_h, wcS, GS.dv, wpr, cv, pre, s_scan, &s_v[SV_NRUNS], s_runs, glob_runs, A.run_cap);
         SIL_TICK(10);
+        // A single component is kept whatever its size (it is the largest when none reaches min_size): the mask
+        // stays as it is.
+        {
+            int roots = 0;
+            for (int r = t; r < cc.n; r += FX_BLOCK)
+                roots += cc.parent[r] == (uint32_t)r ? 1 : 0;
+#pragma unroll
+            for (int o = FX_WAVE / 2; o > 0; o >>= 1)
+                roots += __shfl_xor(roots, o, FX_WAVE);
+            if (fx_lane() == 0 && roots)
+                atomicAdd(&s_v[SV_NROOT_CC], roots);
+            __syncthreads();
+        }
+        const bool one_cc = s_v[SV_NROOT_CC] == 1;   // block-uniform
+        const uint32_t *mK = one_cc ? mB : mA;       // the kept pixels
+        if (!one_cc) {
         // component sizes
         for (int wi = t; wi < nwS; wi += FX_BLOCK) {
             const int y = sil_div(wi, GS.dv), w = wi - y * wcS;
@@ -1560,6 +1596,7 @@ __global__ __launch_bounds__(FX_BLOCK, 5) void sil_mask_kernel(SilArgs A)
         }
         __syncthreads();
 
+        }
         SIL_TICK(12);
         // ---- centred paste on the res x res canvas
         const int px0 = (res - new_w) / 2, py0 = (res - new_h) / 2;
@@ -1572,7 +1609,7 @@ __global__ __launch_bounds__(FX_BLOCK, 5) void sil_mask_kernel(SilArgs A)
                 uint32_t o[4] = {0u, 0u, 0u, 0u};
                 const int x = X0 - px0;  // mask column of the chunk's first pixel
                 if (y >= 0 && y < new_h && x > -16 && x < new_w) {
-                    const uint32_t *r = mA + y * wpr;
+                    const uint32_t *r = mK + y * wpr;
                     const int w0 = x >> 5;  // floor, also for negative x
                     const uint32_t lo = w0 >= 0 && w0 < wcS ? r[w0] : 0u;
                     const uint32_t hi = w0 + 1 >= 0 && w0 + 1 < wcS ? r[w0 + 1] : 0u;
@@ -1588,7 +1625,7 @@ __global__ __launch_bounds__(FX_BLOCK, 5) void sil_mask_kernel(SilArgs A)
                 const int Y = pi / res, X = pi - Y * res;
                 const int y = Y - py0, x = X - px0;
                 uint8_t v = 0;
-                if (y >= 0 && y < new_h && x >= 0 && x < new_w && ((mA[y * wpr + (x >> 5)] >> (x & 31)) & 1u))
+                if (y >= 0 && y < new_h && x >= 0 && x < new_w && ((mK[y * wpr + (x >> 5)] >> (x & 31)) & 1u))
                     v = 255;
                 out[pi] = v;
             }
