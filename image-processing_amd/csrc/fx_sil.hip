@@ -251,6 +251,14 @@ __device__ __forceinline__ int sil_refl101(int i, int n)
 
 constexpr int SIL_CV_HIST_COPIES = 4, SIL_CV_HIST_PITCH = 257;
 
+// a + e + 4 (b + d) + 6 c + k in four full-rate instructions (two three-operand additions, two shift-and-adds);
+// written as a product, 6 c becomes a 32-bit multiply, which issues at a quarter of the rate.
+__device__ __forceinline__ uint32_t sil_taps5(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t e, uint32_t k)
+{
+    const uint32_t inner = b + d + c, outer = a + e + k;
+    return (inner << 2) + ((c << 1) + outer);
+}
+
 template <bool ALIGNED>
 __global__ __launch_bounds__(FX_BLOCK) void sil_blur_cv_kernel(SilArgs A)
 {
@@ -305,7 +313,7 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_blur_cv_kernel(SilArgs A)
             uint32_t o[8];
 #pragma unroll
             for (int k = 0; k < 8; k++)
-                o[k] = P[2 * k] + P[2 * k + 4] + 4u * (P[2 * k + 1] + P[2 * k + 3]) + 6u * P[2 * k + 2];
+                o[k] = sil_taps5(P[2 * k], P[2 * k + 1], P[2 * k + 2], P[2 * k + 3], P[2 * k + 4], 0u);
             *dst_lo = make_uint4(o[0], o[1], o[2], o[3]);
             *dst_hi = make_uint4(o[4], o[5], o[6], o[7]);
         } else {
@@ -351,7 +359,7 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_blur_cv_kernel(SilArgs A)
             if (!rep)
                 return;
             const uint32_t p0 = prev_lo & 255u;
-            if (live >= 8 && prev_lo == p0 * 0x01010101u && prev_hi == prev_lo) {
+            if (live >= 8 && prev_lo == __builtin_amdgcn_perm(0u, prev_lo, 0u) && prev_hi == prev_lo) {   // eight equal bytes
                 atomicAdd(&my_hist[p0], 8u * rep);
             } else {
 #pragma unroll
@@ -361,17 +369,19 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_blur_cv_kernel(SilArgs A)
             }
             rep = 0;
         };
-        auto pack = [](uint32_t ta, uint32_t tb) {
-            return ((ta >> 8) & 255u) | ((ta >> 24) << 8) | (((tb >> 8) & 255u) << 16) | ((tb >> 24) << 24);
-        };
-        for (int y = y0; y < y1; y++) {
-            const uint4 c4 = ld(y + 4);
-            const uint32_t ta = c0.x + c4.x + 4u * (c1.x + c3.x) + 6u * c2.x + 0x00800080u;
-            const uint32_t tb = c0.y + c4.y + 4u * (c1.y + c3.y) + 6u * c2.y + 0x00800080u;
-            const uint32_t tc = c0.z + c4.z + 4u * (c1.z + c3.z) + 6u * c2.z + 0x00800080u;
-            const uint32_t td = c0.w + c4.w + 4u * (c1.w + c3.w) + 6u * c2.w + 0x00800080u;
+        // the high bytes of the four 16-bit fields of (ta, tb): one byte permute
+        auto pack = [](uint32_t ta, uint32_t tb) { return __builtin_amdgcn_perm(tb, ta, 0x07050301u); };
+        uint8_t *po = out + (int64_t)(r0 + y0) * W + x;
+        // (unrolled by five, the five rows of the window rotate through the registers without moves)
+        const uint16_t *nxt = col + (size_t)(y0 + 4) * Wp;   // the row entering the window
+#pragma unroll 5
+        for (int y = y0; y < y1; y++, po += W, nxt += Wp) {
+            const uint4 c4 = *(const uint4 *)nxt;
+            const uint32_t ta = sil_taps5(c0.x, c1.x, c2.x, c3.x, c4.x, 0x00800080u);
+            const uint32_t tb = sil_taps5(c0.y, c1.y, c2.y, c3.y, c4.y, 0x00800080u);
+            const uint32_t tc = sil_taps5(c0.z, c1.z, c2.z, c3.z, c4.z, 0x00800080u);
+            const uint32_t td = sil_taps5(c0.w, c1.w, c2.w, c3.w, c4.w, 0x00800080u);
             const uint32_t o_lo = pack(ta, tb), o_hi = pack(tc, td);
-            uint8_t *po = out + (int64_t)(r0 + y) * W + x;
             if (row_qwords) {
                 *(uint2 *)po = make_uint2(o_lo, o_hi);
             } else {
