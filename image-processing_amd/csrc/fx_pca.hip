@@ -370,9 +370,11 @@ __device__ __forceinline__ void pca_sets_reg_body(const PcaArgs &A, const int64_
             const int p = lane + FX_WAVE * k;
             have[k] = p < n;
             x[k] = y[k] = z[k] = 0.0f;
-            if (have[k]) {
-                const float *q = sv.base + 3 * p;
-                x[k] = q[0], y[k] = q[1], z[k] = q[2];
+            if (have[k]) {   // 2-D points are (x, y, 0)
+                const float *q = sv.base + A.dims * p;
+                x[k] = q[0], y[k] = q[1];
+                if (A.dims == 3)
+                    z[k] = q[2];
             }
         }
     } else {
@@ -1308,8 +1310,8 @@ int launch_reg_sets(const PcaArgs &A, int64_t max_points, bool ragged, hipStream
 
 int launch_small_sets(const PcaArgs &A, int64_t max_points, hipStream_t s)
 {
-    if (A.dims == 3 && max_points > REG_SET_MAX_POINTS && max_points <= 2 * REG_SET_MAX_POINTS) {
-        // 3-D sets of 1025..2048 points: the register kernel with 32 points per lane
+    if (max_points > REG_SET_MAX_POINTS && max_points <= 2 * REG_SET_MAX_POINTS) {
+        // sets of 1025..2048 points: the register kernel with 32 points per lane
         constexpr int NW = FX_PCA_NW;
         const int64_t blocks = (A.n_sets + NW - 1) / NW;
         FX_REQUIRE(blocks <= 0x7fffffffLL, "fx_pca_batch_f32: too many sets for one launch");
@@ -1533,13 +1535,13 @@ int launch_ragged_on_device(const PcaArgs &A, int64_t B, int64_t total, FxCallGu
     Wk.n_clouds_dev = L.counts + 2;
 
     FX_HIP_CHECK(hipMemsetAsync(L.counts, 0, counts_bytes, s));
-    const int64_t reg_max = A.dims == 3 ? REG_SET_MAX_POINTS : -1;   // 2-D sets take the LDS kernel
+    const int64_t reg_max = REG_SET_MAX_POINTS;
     hipLaunchKernelGGL(pca_classify_kernel, dim3((unsigned)((B + FX_BLOCK - 1) / FX_BLOCK)), dim3(FX_BLOCK), 0, s, A, L, B,
                        reg_max);
     FX_HIP_CHECK(hipGetLastError());
     FxProfileScope prof(s);
     int rc = FX_OK;
-    if (A.dims == 3) {
+    {
         PcaArgs S = A;
         S.set_ids = L.reg_ids;
         S.n_sets = B;                 // sizes the grid; the kernel reads the true count
@@ -1605,8 +1607,8 @@ extern "C" int fx_pca_batch_f32(const float *d_pts, const int64_t *d_offsets, in
     FxCallGuard guard(s);
 
     if (!d_offsets) {
-        const bool reg_ok = dims == 3 && N >= 3 && N <= REG_SET_MAX_POINTS;
-        if (reg_ok && (N == 256 || N == 512 || N == 1024) && (uintptr_t)d_pts % 16 == 0) {
+        const bool reg_ok = N >= 3 && N <= REG_SET_MAX_POINTS;
+        if (reg_ok && dims == 3 && (N == 256 || N == 512 || N == 1024) && (uintptr_t)d_pts % 16 == 0) {
             // pca_sets_full_kernel's list of sets for pca_sets_redo_kernel
             int32_t *redo = (int32_t *)guard.scratch(((size_t)B + 64) * sizeof(int32_t), 0);
             if (!redo)
@@ -1616,7 +1618,7 @@ extern "C" int fx_pca_batch_f32(const float *d_pts, const int64_t *d_offsets, in
         }
         FxProfileScope prof(s);
         if (reg_ok)
-            return launch_reg_sets(A, N, N % 4 != 0 || (uintptr_t)d_pts % 16 != 0, s);
+            return launch_reg_sets(A, N, dims != 3 || N % 4 != 0 || (uintptr_t)d_pts % 16 != 0, s);
         if (N <= WAVE_SET_MAX_POINTS)
             return launch_small_sets(A, N < 3 ? 3 : N, s);
         int32_t *sets = (int32_t *)malloc((size_t)B * sizeof(int32_t));
@@ -1669,7 +1671,7 @@ extern "C" int fx_pca_batch_f32(const float *d_pts, const int64_t *d_offsets, in
         return FX_ENOMEM;
     }
     // work list: sets for the register kernel, then those for the LDS kernel, then the large clouds
-    const int64_t reg_max = dims == 3 ? REG_SET_MAX_POINTS : -1;
+    const int64_t reg_max = REG_SET_MAX_POINTS;
     int64_t n_reg = 0, n_small = 0, n_large = 0, max_reg = 3, max_small = 3;
     bool ok = true;
     for (int64_t b = 0; b < B; b++) {

@@ -98,7 +98,7 @@ def test_ragged_batch_and_2d(gpu, oracle):
     r2 = eng.pca_batch(torch.from_numpy(p2).to(gpu), None, 8, False, eig=True)
     p3 = np.concatenate([p2, np.zeros((4, 500, 1), np.float32)], axis=2)
     r3 = eng.pca_batch(torch.from_numpy(p3).to(gpu), None, 8, False, eig=True)
-    # the 2-D call runs the LDS kernel, the 3-D one the register kernel: same values up to summation order
+    # the 2-D call loads point by point, the 3-D one four points at a time: same values up to summation order
     assert torch.allclose(r2["out"], r3["out"], rtol=1e-6, atol=0)
     assert torch.allclose(r2["eig"][:, :3], r3["eig"][:, :3], rtol=1e-12, atol=0)
     assert torch.all((r2["eig"][:, 3:] * r3["eig"][:, 3:]).sum(dim=1).abs() > 1 - 1e-12)
@@ -108,7 +108,7 @@ def test_ragged_batch_and_2d(gpu, oracle):
 @pytest.mark.parametrize("normalize", [False, True])
 def test_variable_size_clouds_tail_config(gpu, oracle, normalize):
     """Clouds with log-uniform sizes from 1e3 to 1.5e6 points in one ragged batch
-    (the load-imbalance configuration): small ones take the LDS kernel, large
+    (the load-imbalance configuration): sets up to 2048 points take the register kernels, larger
     ones are cut into 16384-point chunks spread over the chip."""
     import torch
     eng = pkg("engine")

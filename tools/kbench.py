@@ -151,6 +151,24 @@ if __name__ == "__main__":
             for _ in range(5): eng.pca_batch(pts, d_off)
             torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5 * 1e3
             print(f"pca ragged B={B} sizes {lo}..{hi}: {dt:.3f} ms per call  {off[-1]*12/dt/1e6:.0f} GB/s", flush=True)
+        # 2-D sets (contour points as a separate call): uniform and ragged
+        pts2 = torch.randn((300000, 512, 2), dtype=torch.float32, device=dev)
+        for _ in range(2): eng.pca_batch(pts2, None)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5): eng.pca_batch(pts2, None)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5 * 1e3
+        print(f"pca 2-D B=300000 N=512: {dt:.3f} ms per call  {pts2.numel()*4/dt/1e6:.0f} GB/s", flush=True)
+        sizes = rng.integers(100, 2049, 200000)
+        off = np.zeros(200001, dtype=np.int64); np.cumsum(sizes, out=off[1:])
+        pts2 = torch.randn((int(off[-1]), 2), dtype=torch.float32, device=dev)
+        d_off = torch.from_numpy(off).to(dev)
+        for _ in range(2): eng.pca_batch(pts2, d_off)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5): eng.pca_batch(pts2, d_off)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5 * 1e3
+        print(f"pca 2-D ragged B=200000 sizes 100..2048: {dt:.3f} ms per call  {off[-1]*8/dt/1e6:.0f} GB/s", flush=True)
     elif what == "sil1":
         ms, gbps = time_sil(20000, 224, 224, 224, reps=3)
         print(f"sil B=20000 224x224->224: {ms:.3f} ms  {gbps:.0f} GB/s", flush=True)
