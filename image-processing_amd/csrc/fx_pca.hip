@@ -596,12 +596,12 @@ __global__ __launch_bounds__(FX_WAVE *NW, PPL > 16 ? 2 : FX_PCA_WAVES) void pca_
 }
 
 // The sets pca_sets_full_kernel hands back (A.set_ids, their number in *A.n_sets_dev): a small grid walks the list.
-template <int PPL, int NW>
+template <int PPL, int NW, bool RAGGED = false>
 __global__ __launch_bounds__(FX_WAVE *NW, FX_PCA_WAVES) void pca_sets_redo_kernel(PcaArgs A)
 {
     const int64_t n_sets = (int64_t)*A.n_sets_dev;
     for (int64_t blk = blockIdx.x; blk * NW < n_sets; blk += gridDim.x) {
-        pca_sets_reg_body<PPL, false, NW>(A, blk, n_sets);
+        pca_sets_reg_body<PPL, RAGGED, NW>(A, blk, n_sets);
         __syncthreads();
     }
 }
@@ -890,6 +890,311 @@ __global__ __launch_bounds__(FX_WAVE *NW, PPL <= 8 ? 5 : FX_PCA_WAVES) void pca_
             A.out[set * width + lane] = rec->head[lane];
         if (live && A.eig && lane < 6)
             A.eig[set * 6 + lane] = rec->lam[lane];   // lam[3] and v1[3] lie one after the other
+    }
+}
+
+// ------------------------------------------------ small sets: four per wave
+// Sets of up to 256 points (2-D or 3-D, any alignment): a wave takes four sets, 16 lanes each, lane r of a
+// set holding its points r, r + 16, ...  What is per set and serial -- mean, covariance, eigen-solve, head,
+// float32 coefficients -- is computed by every lane of the set's row (the same instructions serve the four
+// sets of the wave at once; the row sums come from an exchange butterfly, which leaves bit-identical totals in
+// all 16 lanes, so the lanes of a row agree on everything that follows).  No block barrier: waves are
+// independent.  Bins as in pca_sets_full_kernel: one pass with the float32 scale, the points float32 cannot
+// settle go to a list of the wave (tagged with their row) and are evaluated in float64 afterwards, a lane per
+// listed point; the exact maximum of a row is an LDS atomic maximum over its listed points.  Sets that pass
+// cannot take (projections at rounding level, a list that overflows) go to the redo list.
+constexpr int QUAD_SETS = 4, QUAD_LANES = FX_WAVE / QUAD_SETS, QUAD_PPL = 16;
+constexpr int64_t QUAD_MAX_POINTS = QUAD_LANES * QUAD_PPL;
+constexpr int QUAD_COPIES = 4, QUAD_PITCH = HIST_MAX + 1, QUAD_LIST_CAP = 96;
+struct QuadRec {
+    double mean[3], v1[3], rmax;   // rmax = 0: no scaling
+    float q[4];                    // float32 bin coordinate: |q[0..2] . x - q[3]|
+};
+
+template <int CTRL>
+__device__ __forceinline__ double quad_xchg_f64(double v)
+{
+    return fx_dpp_f64<CTRL, 0xf>(v);
+}
+// sum / maximum over the 16 lanes of a row; every lane gets the same bits (each step combines a lane's value
+// with its partner's, and a + b == b + a)
+__device__ __forceinline__ double quad_row_sum(double v)
+{
+    v += quad_xchg_f64<0xB1>(v);    // lane ^ 1
+    v += quad_xchg_f64<0x4E>(v);    // lane ^ 2
+    v += quad_xchg_f64<0x141>(v);   // 7 - lane within half a row
+    v += quad_xchg_f64<0x140>(v);   // 15 - lane
+    return v;
+}
+__device__ __forceinline__ double quad_row_max(double v)
+{
+    v = fmax(v, quad_xchg_f64<0xB1>(v));
+    v = fmax(v, quad_xchg_f64<0x4E>(v));
+    v = fmax(v, quad_xchg_f64<0x141>(v));
+    v = fmax(v, quad_xchg_f64<0x140>(v));
+    return v;
+}
+__device__ __forceinline__ uint32_t quad_row_max_u32(uint32_t v)
+{
+    const auto step = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+    v = step(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false));
+    v = step(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false));
+    v = step(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false));
+    v = step(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, false));
+    return v;
+}
+
+template <int NW>
+__global__ __launch_bounds__(FX_WAVE *NW, 3) void pca_sets_quad_kernel(PcaArgs A, double inv_nb)
+{
+    __shared__ uint32_t hist_all[NW][QUAD_SETS * QUAD_COPIES * QUAD_PITCH];
+    __shared__ float4 list_all[NW][QUAD_LIST_CAP + FX_WAVE];
+    __shared__ QuadRec rec_all[NW][QUAD_SETS];
+    __shared__ unsigned long long top_all[NW][QUAD_SETS];
+    const int lane = fx_lane(), wave = fx_wave();
+    const int row = lane / QUAD_LANES, r = lane % QUAD_LANES;
+    const int64_t n_sets = A.n_sets_dev ? (int64_t)*A.n_sets_dev : A.n_sets;
+    const int64_t first = ((int64_t)blockIdx.x * NW + wave) * QUAD_SETS;
+    if (first >= n_sets)
+        return;   // the whole wave; there is no block barrier below
+    const int64_t slot = first + row;
+    const bool in_range = slot < n_sets;
+    const SetView sv = resolve_set(A, in_range ? slot : first);
+    const int64_t set = sv.set;
+    const int nb = A.n_bins, width = 9 + nb, dims = A.dims;
+    const bool small = sv.n <= QUAD_MAX_POINTS;
+    const bool live = in_range && sv.n >= 3 && small;
+    const int n = live ? (int)sv.n : 0;
+    if (in_range && sv.n < 3)
+        write_nan_row(A, set, r, QUAD_LANES);
+    auto to_redo = [&](bool which) {   // lane 0 of every row for which `which` holds hands its set on
+        if (which && r == 0)
+            A.redo_list[atomicAdd(A.redo_count, 1)] = (int32_t)set;
+    };
+    to_redo(in_range && !small);   // (the dispatcher sends no such set here)
+
+    uint32_t *hist = hist_all[wave];
+    for (int k = lane; k < QUAD_SETS * QUAD_COPIES * QUAD_PITCH; k += FX_WAVE)
+        hist[k] = 0;
+    uint32_t *my_hist = hist + (row * QUAD_COPIES + (r % QUAD_COPIES)) * QUAD_PITCH;
+
+    // Lane r holds the points r, r + 16, ...; the slots past the end of the set hold the set's first point, which
+    // is the pivot of the sums: such a slot adds exact zeros to them, and a copy of a point changes no maximum.
+    // (No predicates until the histogram.)
+    float x[QUAD_PPL], y[QUAD_PPL], z[QUAD_PPL];
+    float kx32 = 0.0f, ky32 = 0.0f, kz32 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < QUAD_PPL; k++)
+        x[k] = y[k] = z[k] = 0.0f;
+    if (live) {
+        struct P3 {
+            float a, b, c;
+        };
+        struct P2 {
+            float a, b;
+        };
+        if (dims == 3) {
+#pragma unroll
+            for (int k = 0; k < QUAD_PPL; k++) {
+                const int p = r + QUAD_LANES * k;
+                const P3 v = *reinterpret_cast<const P3 *>(sv.base + 3 * (p < n ? p : 0));
+                x[k] = v.a, y[k] = v.b, z[k] = v.c;
+            }
+            const P3 v = *reinterpret_cast<const P3 *>(sv.base);
+            kx32 = v.a, ky32 = v.b, kz32 = v.c;
+        } else {   // 2-D points are (x, y, 0)
+#pragma unroll
+            for (int k = 0; k < QUAD_PPL; k++) {
+                const int p = r + QUAD_LANES * k;
+                const P2 v = *reinterpret_cast<const P2 *>(sv.base + 2 * (p < n ? p : 0));
+                x[k] = v.a, y[k] = v.b;
+            }
+            const P2 v = *reinterpret_cast<const P2 *>(sv.base);
+            kx32 = v.a, ky32 = v.b;
+        }
+    }
+    const double kx = kx32, ky = ky32, kz = kz32;
+    double v9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < QUAD_PPL; k++) {
+        const double dx = (double)x[k] - kx, dy = (double)y[k] - ky, dz = (double)z[k] - kz;
+        v9[0] += dx;
+        v9[1] += dy;
+        v9[2] += dz;
+        v9[3] = fma(dx, dx, v9[3]);
+        v9[4] = fma(dx, dy, v9[4]);
+        v9[5] = fma(dx, dz, v9[5]);
+        v9[6] = fma(dy, dy, v9[6]);
+        v9[7] = fma(dy, dz, v9[7]);
+        v9[8] = fma(dz, dz, v9[8]);
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++)
+        v9[k] = quad_row_sum(v9[k]);
+    const double dn = live ? (double)n : 3.0;
+    const double inv_n = 1.0 / dn;
+    const double ox = v9[0] * inv_n, oy = v9[1] * inv_n, oz = v9[2] * inv_n;   // mean - pivot
+    const double mx = kx + ox, my = ky + oy, mz = kz + oz;
+    double S[6];
+    S[0] = fma(-v9[0], ox, v9[3]);
+    S[1] = fma(-v9[0], oy, v9[4]);
+    S[2] = fma(-v9[0], oz, v9[5]);
+    S[3] = fma(-v9[1], oy, v9[6]);
+    S[4] = fma(-v9[1], oz, v9[7]);
+    S[5] = fma(-v9[2], oz, v9[8]);
+    // every centred point lies within sqrt(sum of squared distances) of the mean
+    const float reach32 = sqrtf((float)(S[0] + S[3] + S[5])) * 1.000001f;
+    double rmax = 0.0;
+    if (A.normalize) {
+        double r2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < QUAD_PPL; k++) {
+            const double dx = (double)x[k] - mx, dy = (double)y[k] - my, dz = (double)z[k] - mz;
+            r2 = fmax(r2, dx * dx + dy * dy + dz * dz);
+        }
+        rmax = sqrt(quad_row_max(r2));
+    }
+    const bool scale = A.normalize && rmax > 0.0;
+    double wcov = 1.0 / (dn - 1.0);   // np.cov multiplies by 1/(n-1)
+    if (scale)
+        wcov *= 1.0 / (rmax * rmax);
+    double lam[3] = {0.0, 0.0, 0.0}, v1[3] = {1.0, 0.0, 0.0};
+    // the direct solve where it applies (well separated, clearly positive eigenvalues), the sweeps otherwise
+    if (!fx_eig3_direct(S[0] * wcov, S[1] * wcov, S[2] * wcov, S[3] * wcov, S[4] * wcov, S[5] * wcov, lam, v1))
+        fx_eig3<true>(S[0] * wcov, S[1] * wcov, S[2] * wcov, S[3] * wcov, S[4] * wcov, S[5] * wcov, lam, v1);
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+        lam[q] = lam[q] < 0.0 ? 0.0 : lam[q];
+    {
+        // the nine scalars of the head, lane r of the row computing entry r: one division
+        const double trace = lam[0] + lam[1] + lam[2];
+        const double safe = trace > 1e-12 ? trace : 1e-12;
+        const int e = r < 9 ? r : 0;
+        const double num = (e == 0 || e == 3 || e == 6) ? lam[0] : (e == 1 || e == 4 || e == 7) ? lam[1] : (e == 2 || e == 5) ? lam[2] : trace;
+        const double den = e < 3 || e == 8 ? 1.0 : e < 6 ? safe : e == 6 ? lam[1] + 1e-12 : lam[2] + 1e-12;
+        if (live && r < 9)
+            A.out[set * width + r] = (float)(num / den);
+        if (live && A.eig && r < 6) {
+            double ev = lam[0];
+            ev = r == 1 ? lam[1] : ev;
+            ev = r == 2 ? lam[2] : ev;
+            ev = r == 3 ? v1[0] : ev;
+            ev = r == 4 ? v1[1] : ev;
+            ev = r == 5 ? v1[2] : ev;
+            A.eig[set * 6 + r] = ev;
+        }
+    }
+    // float32 value of a projection: v.x - v.mean in three FMAs; eps32 bounds its error (see pca_sets_full_kernel)
+    const float w32 = scale ? (float)(1.0 / rmax) : 1.0f;
+    const float vx32 = (float)v1[0] * w32, vy32 = (float)v1[1] * w32, vz32 = (float)v1[2] * w32;
+    const float c32 = (float)(fma(v1[2], mz, fma(v1[1], my, v1[0] * mx))) * w32;
+    const float m1 = fabsf((float)mx) + fabsf((float)my) + fabsf((float)mz);
+    const float eps32 = 1e-6f * w32 * (2.0f * m1 + reach32) + 1e-37f;
+    float top32 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < QUAD_PPL; k++)
+        top32 = fmaxf(top32, fabsf(fmaf(z[k], vz32, fmaf(y[k], vy32, fmaf(x[k], vx32, -c32)))));
+    top32 = __int_as_float((int)quad_row_max_u32((uint32_t)__float_as_int(top32)));
+    // rows whose projections are at rounding level are redone in float64 throughout
+    bool act = live && top32 > 8.0f * eps32;
+    to_redo(live && !act);
+    const float inv32 = act ? (float)nb / top32 : 0.0f;
+    const float qx = vx32 * inv32, qy = vy32 * inv32, qz = vz32 * inv32, qc = c32 * inv32;
+    const float margin = (3.0f * eps32 + 6e-7f * top32) * inv32 + 1e-5f * (float)nb;
+    if (r == 0) {
+        QuadRec *rec = &rec_all[wave][row];
+        rec->mean[0] = mx, rec->mean[1] = my, rec->mean[2] = mz;
+        rec->v1[0] = v1[0], rec->v1[1] = v1[1], rec->v1[2] = v1[2];
+        rec->rmax = scale ? rmax : 0.0;
+        rec->q[0] = qx, rec->q[1] = qy, rec->q[2] = qz, rec->q[3] = qc;
+        top_all[wave][row] = 0ull;
+    }
+    auto wave_sync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    wave_sync();
+    // one pass settles the bins of every point float32 can settle; the others are listed with their row
+    float4 *list = list_all[wave];
+    int n_slow = 0;
+    bool overflow = false;
+    const int n_act = act ? n : 0;
+#pragma unroll
+    for (int k = 0; k < QUAD_PPL; k++) {
+        const bool hv = r + QUAD_LANES * k < n_act;
+        const float q = fabsf(fmaf(z[k], qz, fmaf(y[k], qy, fmaf(x[k], qx, -qc))));
+        const bool slow = hv && fabsf(q - rintf(q)) < margin;
+        if (hv)
+            atomicAdd(&my_hist[(int)q], 1u);   // q <= n_bins + margin: the row has a spare entry
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(slow);
+        if (mask && !overflow) {
+            if (n_slow > QUAD_LIST_CAP) {
+                overflow = true;
+            } else {
+                const int pos = n_slow + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                if (slow)
+                    list[pos] = make_float4(x[k], y[k], z[k], __int_as_float(row));
+                n_slow += __builtin_popcountll(mask);
+            }
+        }
+    }
+    if (overflow) {   // wave-uniform: degenerate sets (most points at one |projection|)
+        to_redo(act);
+        return;
+    }
+    wave_sync();
+    // float64 value of a listed point (the formula of record), with the record of the point's row
+    auto proj = [&](const QuadRec *rec, float px, float py, float pz) -> double {
+        double dx = (double)px - rec->mean[0], dy = (double)py - rec->mean[1], dz = (double)pz - rec->mean[2];
+        if (rec->rmax > 0.0) {
+            const double rm = rec->rmax;
+            dx /= rm;
+            dy /= rm;
+            dz /= rm;
+        }
+        return fabs(fma(dz, rec->v1[2], fma(dy, rec->v1[1], dx * rec->v1[0])));
+    };
+    for (int e = lane; e < n_slow; e += FX_WAVE) {
+        const float4 pt = list[e];
+        const int er = __float_as_int(pt.w);
+        const double pv = proj(&rec_all[wave][er], pt.x, pt.y, pt.z);
+        atomicMax(&top_all[wave][er], (unsigned long long)__double_as_longlong(pv));   // pv >= 0: the bits order like the values
+    }
+    wave_sync();
+    {
+        const double mytop = __longlong_as_double((long long)top_all[wave][row]);
+        const bool sane = mytop > 1e-280 && mytop < 1e280;   // the shortcuts below assume a plain double
+        to_redo(act && !sane);
+        act = act && sane;
+    }
+    for (int e = lane; e < n_slow; e += FX_WAVE) {
+        const float4 pt = list[e];
+        const int er = __float_as_int(pt.w);
+        const QuadRec *rec = &rec_all[wave][er];
+        const double top = __longlong_as_double((long long)top_all[wave][er]);
+        if (!(top > 1e-280 && top < 1e280))
+            continue;
+        // step = top / n_bins, correctly rounded, from the host's correctly rounded 1 / n_bins (two residual
+        // corrections: the first makes the quotient faithful, the second then rounds it correctly)
+        const double dnb = (double)nb;
+        double step = top * inv_nb;
+        step = fma(fma(-dnb, step, top), inv_nb, step);
+        step = fma(fma(-dnb, step, top), inv_nb, step);
+        const double inv_step = dnb * __builtin_amdgcn_rcp(top);
+        uint32_t *h = hist + (er * QUAD_COPIES + (lane % QUAD_COPIES)) * QUAD_PITCH;
+        const float q = fabsf(fmaf(pt.z, rec->q[2], fmaf(pt.y, rec->q[1], fmaf(pt.x, rec->q[0], -rec->q[3]))));
+        atomicSub(&h[(int)q], 1u);   // the same arithmetic as in the pass: the same bin
+        atomicAdd(&h[fx_hist_bin_near(proj(rec, pt.x, pt.y, pt.z), step, inv_step, nb)], 1u);
+    }
+    wave_sync();
+    if (act) {
+        for (int i = r; i < nb; i += QUAD_LANES) {
+            uint32_t h = 0;
+#pragma unroll
+            for (int c = 0; c < QUAD_COPIES; c++)
+                h += hist[(row * QUAD_COPIES + c) * QUAD_PITCH + i];
+            A.out[set * width + 9 + i] = (float)h / (float)n;
+        }
     }
 }
 
@@ -1275,16 +1580,34 @@ int launch_full_sets(const PcaArgs &A, hipStream_t s)
     return FX_OK;
 }
 
+// Sets of up to QUAD_MAX_POINTS points, four per wave; A.redo_list / A.redo_count take the sets left over.
+int launch_quad_sets(const PcaArgs &A, hipStream_t s)
+{
+    constexpr int NW = FX_PCA_NW;
+    const int64_t waves = (A.n_sets + QUAD_SETS - 1) / QUAD_SETS;
+    const int64_t blocks = (waves + NW - 1) / NW;
+    FX_REQUIRE(blocks <= 0x7fffffffLL, "fx_pca_batch_f32: too many sets for one launch");
+    FX_REQUIRE(A.redo_list && A.redo_count, "fx_pca_batch_f32: no list for the sets to redo");
+    FX_HIP_CHECK(hipMemsetAsync(A.redo_count, 0, sizeof(int32_t), s));
+    hipLaunchKernelGGL((pca_sets_quad_kernel<NW>), dim3((unsigned)blocks), dim3(FX_WAVE * NW), 0, s, A, 1.0 / (double)A.n_bins);
+    PcaArgs R = A;
+    R.set_ids = A.redo_list;
+    R.n_sets_dev = A.redo_count;
+    hipLaunchKernelGGL((pca_sets_redo_kernel<4, NW, true>), dim3((unsigned)(blocks < 256 ? blocks : 256)), dim3(FX_WAVE * NW), 0, s, R);
+    FX_HIP_CHECK(hipGetLastError());
+    return FX_OK;
+}
+
 int launch_reg_sets(const PcaArgs &A, int64_t max_points, bool ragged, hipStream_t s)
 {
     constexpr int NW = FX_PCA_NW;  // sets (waves) per block
+    if (max_points <= QUAD_MAX_POINTS && A.redo_list)
+        return launch_quad_sets(A, s);
     if (!ragged && !A.offsets && !A.set_ids) {
         if (max_points == 1024)
             return launch_full_sets<16>(A, s);
         if (max_points == 512)
             return launch_full_sets<8>(A, s);
-        if (max_points == 256)
-            return launch_full_sets<4>(A, s);
     }
     const int64_t blocks = (A.n_sets + NW - 1) / NW;
     FX_REQUIRE(blocks <= 0x7fffffffLL, "fx_pca_batch_f32: too many sets for one launch");
@@ -1332,9 +1655,10 @@ int launch_small_sets(const PcaArgs &A, int64_t max_points, hipStream_t s)
 // launches that consume them are sized by upper bounds and their surplus blocks
 // leave at once (set kernels) or their blocks walk the list (cloud chain).
 struct RaggedLists {
-    int32_t *counts;       // [0] register sets, [1] LDS sets, [2] large clouds, [3] chunks
+    int32_t *counts;       // [0] register sets, [1] sets of 1025..2048 points, [2] large clouds, [3] chunks, [4] small sets
     int32_t *reg_ids;      // [B]
     int32_t *lds_ids;      // [B]
+    int32_t *quad_ids;     // [B] sets of up to QUAD_MAX_POINTS points (four per wave)
     int32_t *cloud_ids;    // [max_clouds]
     int32_t *cloud_first;  // [max_clouds + 1]
     int32_t *chunk_cloud;  // [max_chunks]
@@ -1348,22 +1672,22 @@ __global__ __launch_bounds__(FX_BLOCK) void pca_classify_kernel(PcaArgs A, Ragge
     if (b < B) {
         // a set of fewer than three points (or with decreasing offsets) gets its NaN row from the set kernels
         const int64_t n = A.offsets[b + 1] - A.offsets[b];
-        cls = n <= reg_max ? 0 : n <= WAVE_SET_MAX_POINTS ? 1 : 2;
+        cls = n <= QUAD_MAX_POINTS ? 3 : n <= reg_max ? 0 : n <= WAVE_SET_MAX_POINTS ? 1 : 2;
     }
     const int lane = fx_lane();
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
+    for (int c = 0; c < 4; c++) {
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(cls == c);
         if (!mask)
             continue;
         int base = 0;
         if (lane == __builtin_ctzll(mask))
-            base = atomicAdd(&L.counts[c], (int)__builtin_popcountll(mask));   // one atomic per wave and list
+            base = atomicAdd(&L.counts[c == 3 ? 4 : c], (int)__builtin_popcountll(mask));   // one atomic per wave and list
         base = __builtin_amdgcn_readlane(base, __builtin_ctzll(mask));
         if (cls == c) {
             const int pos = base + (int)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
-            int32_t *list = c == 0 ? L.reg_ids : c == 1 ? L.lds_ids : L.cloud_ids;
-            if (c < 2 || pos < L.max_clouds)
+            int32_t *list = c == 0 ? L.reg_ids : c == 1 ? L.lds_ids : c == 2 ? L.cloud_ids : L.quad_ids;
+            if (c != 2 || pos < L.max_clouds)
                 list[pos] = (int32_t)b;
         }
     }
@@ -1510,8 +1834,9 @@ int launch_ragged_on_device(const PcaArgs &A, int64_t B, int64_t total, FxCallGu
     const size_t part_bytes = align((size_t)max_chunks * PART * sizeof(double));
     const size_t hist_bytes = align((size_t)max_chunks * HIST_MAX * sizeof(uint32_t));
     const size_t state_bytes = align((size_t)max_clouds * STATE * sizeof(double));
+    const size_t redo_bytes = align(((size_t)B + 64) * sizeof(int32_t));
     unsigned char *base = (unsigned char *)guard.scratch(
-        counts_bytes + 2 * ids_bytes + 2 * cid_bytes + cc_bytes + part_bytes + hist_bytes + state_bytes, 2);
+        counts_bytes + 3 * ids_bytes + redo_bytes + 2 * cid_bytes + cc_bytes + part_bytes + hist_bytes + state_bytes, 2);
     if (!base)
         return FX_ENOMEM;
     RaggedLists L;
@@ -1519,6 +1844,9 @@ int launch_ragged_on_device(const PcaArgs &A, int64_t B, int64_t total, FxCallGu
     L.counts = (int32_t *)p, p += counts_bytes;
     L.reg_ids = (int32_t *)p, p += ids_bytes;
     L.lds_ids = (int32_t *)p, p += ids_bytes;
+    L.quad_ids = (int32_t *)p, p += ids_bytes;
+    int32_t *redo = (int32_t *)p;
+    p += redo_bytes;
     L.cloud_ids = (int32_t *)p, p += cid_bytes;
     L.cloud_first = (int32_t *)p, p += cid_bytes;
     L.chunk_cloud = (int32_t *)p, p += cc_bytes;
@@ -1543,8 +1871,17 @@ int launch_ragged_on_device(const PcaArgs &A, int64_t B, int64_t total, FxCallGu
     int rc = FX_OK;
     {
         PcaArgs S = A;
-        S.set_ids = L.reg_ids;
+        S.set_ids = L.quad_ids;
         S.n_sets = B;                 // sizes the grid; the kernel reads the true count
+        S.n_sets_dev = L.counts + 4;
+        S.redo_count = redo;
+        S.redo_list = redo + 64;
+        rc = launch_quad_sets(S, s);
+    }
+    if (rc == FX_OK) {
+        PcaArgs S = A;
+        S.set_ids = L.reg_ids;
+        S.n_sets = B;
         S.n_sets_dev = L.counts + 0;
         rc = launch_reg_sets(S, REG_SET_MAX_POINTS, true, s);
     }
@@ -1608,7 +1945,7 @@ extern "C" int fx_pca_batch_f32(const float *d_pts, const int64_t *d_offsets, in
 
     if (!d_offsets) {
         const bool reg_ok = N >= 3 && N <= REG_SET_MAX_POINTS;
-        if (reg_ok && dims == 3 && (N == 256 || N == 512 || N == 1024) && (uintptr_t)d_pts % 16 == 0) {
+        if (reg_ok && (N <= QUAD_MAX_POINTS || (dims == 3 && (N == 512 || N == 1024) && (uintptr_t)d_pts % 16 == 0))) {
             // pca_sets_full_kernel's list of sets for pca_sets_redo_kernel
             int32_t *redo = (int32_t *)guard.scratch(((size_t)B + 64) * sizeof(int32_t), 0);
             if (!redo)

@@ -224,3 +224,46 @@ def test_ragged_batch_of_many_small_sets_and_bad_offsets(gpu, oracle):
     pts = rng.normal(size=(int(off[-1]), 3)).astype(np.float32)
     out = eng.pca_batch(torch.from_numpy(pts).to(gpu), torch.from_numpy(bad).to(gpu), 8, False)["out"].cpu().numpy()
     assert np.isnan(out[10]).all() and not np.isnan(out[12]).any()
+
+
+@pytest.mark.parametrize("N,dims,normalize,nb", [(3, 3, False, 8), (5, 3, True, 8), (16, 3, False, 4), (17, 2, False, 8),
+                                                 (100, 3, True, 16), (255, 3, False, 8), (256, 3, False, 8),
+                                                 (256, 2, True, 8), (200, 3, False, 64)])
+def test_small_sets_four_per_wave(gpu, oracle, N, dims, normalize, nb):
+    """Uniform batches of up to 256 points per set (four sets share a wave), including the sets that path hands
+    on: identical points, collinear points, two tight clusters, a set far from the origin; 2-D sets are (x, y, 0).
+    The batch size leaves the last wave with one set."""
+    import torch
+    eng = pkg("engine")
+    rng = np.random.default_rng(1000 * N + dims)
+    B = 41
+    pts = (rng.normal(size=(B, N, dims)) * rng.uniform(0.05, 3.0, size=(B, 1, dims))).astype(np.float32)
+    pts[1] = pts[1, 0]                                                  # identical points
+    pts[2] = np.outer(np.linspace(-1.0, 2.0, N), pts[2, 0])             # a line through the origin
+    pts[3, : N // 2] = pts[3, 0]                                        # two clusters (points repeated)
+    pts[3, N // 2:] = pts[3, N - 1]
+    pts[4] += np.float32(4096.0)                                        # far from the origin
+    pts[5] *= np.float32(1e-12)                                         # tiny
+    res = eng.pca_batch(torch.from_numpy(pts).to(gpu), None, nb, normalize, eig=True)
+    torch.cuda.synchronize()
+    out, eig = res["out"].cpu().numpy(), res["eig"].cpu().numpy()
+    ties = 0
+    for b in range(B):
+        p3 = np.zeros((N, 3), dtype=np.float64)
+        p3[:, :dims] = pts[b]
+        ref_out, ref_eig = oracle.compute_pca_features(p3, nb, normalize, return_eig=True)
+        degenerate = ref_eig[2] <= 1e-9 * max(ref_eig[0], 1e-300)
+        if b in (1, 2, 3):   # every point on a bin edge or two: the counts themselves
+            lam1 = max(ref_eig[0], 1e-300)
+            assert np.all(np.abs(eig[b][:3] - ref_eig[:3]) <= 1e-9 * lam1)
+            if b == 1:
+                np.testing.assert_array_equal(out[b, 9:], ref_out[9:])
+            continue
+        got = out[b].copy()
+        if degenerate:
+            # lambda3 is rounding noise (up to 1e-16 lambda1 on either side of zero, a clipped negative where it
+            # falls below), and ratio23 = lambda2 / (lambda3 + 1e-12) shows it at the 1e-3 level
+            assert abs(got[7] - ref_out[7]) <= 2e-2 * abs(ref_out[7])
+            got[7] = ref_out[7]
+        ties += compare_set(got, eig[b], ref_out, ref_eig, N, strict_rel=not degenerate)
+    assert ties <= 3
