@@ -630,9 +630,14 @@ struct SetRec {
     float head[9];
     float pad;
 };
-template <int PPL, int NW, bool NORMALIZE>
-// (sets of 512 points leave room for a fifth wave per SIMD: 12 % faster there; at 1024 points it would spill)
-__global__ __launch_bounds__(FX_WAVE *NW, PPL <= 8 ? 5 : FX_PCA_WAVES) void pca_sets_full_kernel(PcaArgs A, double inv_n, double inv_nm1, double inv_nb)
+// RAGGED: sets of any size up to 64 * PPL points, 2-D or 3-D, any alignment, through set lists and CSR offsets
+// (lane l holds the points l, l + 64, ..., loaded one by one).  The slots past the end of a set hold the set's
+// first point, which is the pivot of the sums: such a slot adds exact zeros to them and, being a copy of a point,
+// changes no maximum, so the passes stay free of predicates; only the histogram add is masked.
+template <int PPL, int NW, bool NORMALIZE, bool RAGGED = false>
+// (sets of 512 points leave room for a fifth wave per SIMD: 12 % faster there; at 1024 points it would spill;
+// 32 points per lane take 96 registers for the coordinates: two waves)
+__global__ __launch_bounds__(FX_WAVE *NW, PPL > 16 ? 2 : (PPL <= 8 && !RAGGED) ? 5 : FX_PCA_WAVES) void pca_sets_full_kernel(PcaArgs A, double inv_n, double inv_nm1, double inv_nb)
 {
     constexpr int HIST_COPIES = 8, HIST_PITCH = HIST_MAX + 1;
     __shared__ uint32_t hist_all[NW][HIST_COPIES * HIST_PITCH];
@@ -640,28 +645,71 @@ __global__ __launch_bounds__(FX_WAVE *NW, PPL <= 8 ? 5 : FX_PCA_WAVES) void pca_
     __shared__ SetRec rec_all[NW];
     static_assert(NW * 16 <= FX_WAVE, "a lane per (set, head scalar)");
     const int lane = fx_lane(), wave = fx_wave();
-    constexpr int n = FX_WAVE * PPL;
     constexpr int G = PPL / 4;  // 4-point groups (48 bytes) per lane
     const int64_t slot = (int64_t)blockIdx.x * NW + wave;
     uint32_t *hist = hist_all[wave];
     uint32_t *my_hist = hist + (lane % HIST_COPIES) * HIST_PITCH;
     const int nb = A.n_bins;
     const int width = 9 + nb;
+    const int64_t n_sets = RAGGED && A.n_sets_dev ? (int64_t)*A.n_sets_dev : A.n_sets;
+    if (RAGGED && (int64_t)blockIdx.x * NW >= n_sets)
+        return;  // a surplus block of a launch sized by an upper bound (the whole block leaves, before any barrier)
 
     {
-        // a wave past the last set stays for the block barriers: it works on the last set and writes nothing
-        const bool live = slot < A.n_sets;
-        const int64_t set = live ? slot : A.n_sets - 1;
-        const float4 *g4 = reinterpret_cast<const float4 *>(A.pts + set * (int64_t)(3 * n));
+        // a wave past the last set, or (RAGGED) with a set of fewer than three points, stays for the block
+        // barriers and writes no features
+        const bool in_range = slot < n_sets;
         float x[PPL], y[PPL], z[PPL];
+        int64_t set;
+        int n;
+        bool live;
+        if (!RAGGED) {
+            n = FX_WAVE * PPL;
+            live = in_range;
+            set = live ? slot : n_sets - 1;   // (works on the last set)
+            const float4 *g4 = reinterpret_cast<const float4 *>(A.pts + set * (int64_t)(3 * n));
 #pragma unroll
-        for (int k = 0; k < G; k++) {
-            const int grp = lane + FX_WAVE * k;  // points 4 * grp .. 4 * grp + 3
-            const float4 a = g4[3 * grp], b = g4[3 * grp + 1], c = g4[3 * grp + 2];
-            x[4 * k] = a.x, y[4 * k] = a.y, z[4 * k] = a.z;
-            x[4 * k + 1] = a.w, y[4 * k + 1] = b.x, z[4 * k + 1] = b.y;
-            x[4 * k + 2] = b.z, y[4 * k + 2] = b.w, z[4 * k + 2] = c.x;
-            x[4 * k + 3] = c.y, y[4 * k + 3] = c.z, z[4 * k + 3] = c.w;
+            for (int k = 0; k < G; k++) {
+                const int grp = lane + FX_WAVE * k;  // points 4 * grp .. 4 * grp + 3
+                const float4 a = g4[3 * grp], b = g4[3 * grp + 1], c = g4[3 * grp + 2];
+                x[4 * k] = a.x, y[4 * k] = a.y, z[4 * k] = a.z;
+                x[4 * k + 1] = a.w, y[4 * k + 1] = b.x, z[4 * k + 1] = b.y;
+                x[4 * k + 2] = b.z, y[4 * k + 2] = b.w, z[4 * k + 2] = c.x;
+                x[4 * k + 3] = c.y, y[4 * k + 3] = c.z, z[4 * k + 3] = c.w;
+            }
+        } else {
+            const SetView sv = resolve_set(A, in_range ? slot : 0);
+            set = sv.set;
+            live = in_range && sv.n >= 3 && sv.n <= FX_WAVE * PPL;
+            n = live ? (int)sv.n : 0;
+            if (in_range && sv.n < 3)
+                write_nan_row(A, set, lane, FX_WAVE);
+#pragma unroll
+            for (int k = 0; k < PPL; k++)
+                x[k] = y[k] = z[k] = 0.0f;
+            if (live) {   // wave-uniform
+                struct P3 {
+                    float a, b, c;
+                };
+                struct P2 {
+                    float a, b;
+                };
+                if (A.dims == 3) {
+#pragma unroll
+                    for (int k = 0; k < PPL; k++) {
+                        const int p = lane + FX_WAVE * k;
+                        const P3 v = *reinterpret_cast<const P3 *>(sv.base + 3 * (p < n ? p : 0));
+                        x[k] = v.a, y[k] = v.b, z[k] = v.c;
+                    }
+                } else {   // 2-D points are (x, y, 0)
+#pragma unroll
+                    for (int k = 0; k < PPL; k++) {
+                        const int p = lane + FX_WAVE * k;
+                        const P2 v = *reinterpret_cast<const P2 *>(sv.base + 2 * (p < n ? p : 0));
+                        x[k] = v.a, y[k] = v.b;
+                    }
+                }
+            }
         }
 #pragma unroll
         for (int k = 0; k < HIST_COPIES; k++)
@@ -696,7 +744,8 @@ __global__ __launch_bounds__(FX_WAVE *NW, PPL <= 8 ? 5 : FX_PCA_WAVES) void pca_
         if (NORMALIZE) {
             // NORMALIZE is a template argument: as a run-time branch it makes the compiler keep all widened
             // coordinates of the first pass alive for this one (48 more registers, one wave less per SIMD)
-            const double mx = kx + slab[RED9_TOT] * inv_n, my = ky + slab[RED9_TOT + 1] * inv_n, mz = kz + slab[RED9_TOT + 2] * inv_n;
+            const double inv_cnt = RAGGED ? 1.0 / (double)(live ? n : 3) : inv_n;
+            const double mx = kx + slab[RED9_TOT] * inv_cnt, my = ky + slab[RED9_TOT + 1] * inv_cnt, mz = kz + slab[RED9_TOT + 2] * inv_cnt;
             double r2 = 0.0;
 #pragma unroll
             for (int i = 0; i < PPL; i++) {
@@ -711,13 +760,16 @@ __global__ __launch_bounds__(FX_WAVE *NW, PPL <= 8 ? 5 : FX_PCA_WAVES) void pca_
             slab[RED9_TOT + 10] = kx;
             slab[RED9_TOT + 11] = ky;
             slab[RED9_TOT + 12] = kz;
+            if (RAGGED)
+                slab[RED9_TOT + 13] = (double)(live ? n : 3);
         }
         __syncthreads();
         if (wave == (int)(blockIdx.x % NW)) {
             if (lane < NW) {
                 const double *t = red_all[lane] + RED9_TOT;
                 SetRec *rec = &rec_all[lane];
-                const double ox = t[0] * inv_n, oy = t[1] * inv_n, oz = t[2] * inv_n;  // mean - pivot
+                const double cnt_inv = RAGGED ? 1.0 / t[13] : inv_n;
+                const double ox = t[0] * cnt_inv, oy = t[1] * cnt_inv, oz = t[2] * cnt_inv;  // mean - pivot
                 const double mx = t[10] + ox, my = t[11] + oy, mz = t[12] + oz;
                 double S[6];
                 S[0] = fma(-t[0], ox, t[3]);
@@ -730,13 +782,17 @@ __global__ __launch_bounds__(FX_WAVE *NW, PPL <= 8 ? 5 : FX_PCA_WAVES) void pca_
                 const float reach32 = sqrtf((float)(S[0] + S[3] + S[5])) * 1.000001f;
                 const double rmax = NORMALIZE ? t[9] : 0.0;
                 const bool scale = NORMALIZE && rmax > 0.0;
-                double wcov = inv_nm1;  // np.cov multiplies by 1/(n-1)
+                double wcov = RAGGED ? 1.0 / (t[13] - 1.0) : inv_nm1;  // np.cov multiplies by 1/(n-1)
                 if (scale)
                     wcov *= 1.0 / (rmax * rmax);
                 double lam[3] = {0.0, 0.0, 0.0}, v1[3] = {0.0, 0.0, 0.0};
                 // Matrices the direct solve does not take (eigenvalues too close, or one next to nothing) go
                 // to pca_sets_redo_kernel with the set.
-                const bool solved = fx_eig3_direct(S[0] * wcov, S[1] * wcov, S[2] * wcov, S[3] * wcov, S[4] * wcov, S[5] * wcov, lam, v1);
+                bool solved = fx_eig3_direct(S[0] * wcov, S[1] * wcov, S[2] * wcov, S[3] * wcov, S[4] * wcov, S[5] * wcov, lam, v1);
+                if (!solved) {   // (a few lanes of one wave in four: the sweeps cost little here)
+                    fx_eig3<true>(S[0] * wcov, S[1] * wcov, S[2] * wcov, S[3] * wcov, S[4] * wcov, S[5] * wcov, lam, v1);
+                    solved = true;
+                }
 #pragma unroll
                 for (int q = 0; q < 3; q++) {
                     rec->lam[q] = lam[q] < 0.0 ? 0.0 : lam[q];
@@ -772,6 +828,8 @@ __global__ __launch_bounds__(FX_WAVE *NW, PPL <= 8 ? 5 : FX_PCA_WAVES) void pca_
         }
         __syncthreads();
         const SetRec *rec = &rec_all[wave];
+        if (RAGGED && !live)
+            return;   // after the block's last barrier
         if (!rec->solved) {   // wave-uniform; after the block's last barrier
             if (live && lane == 0)
                 A.redo_list[atomicAdd(A.redo_count, 1)] = (int32_t)set;
@@ -833,8 +891,10 @@ __global__ __launch_bounds__(FX_WAVE *NW, PPL <= 8 ? 5 : FX_PCA_WAVES) void pca_
                 // every point is counted in the bin float32 gives it (q <= n_bins + margin: the row has a spare
                 // entry); a listed point is taken out of that bin again when the list is evaluated
                 const float q = q32(x[i], y[i], z[i]);
-                const bool slow = fabsf(q - rintf(q)) < margin;
-                atomicAdd(&my_hist[(int)q], 1u);
+                const bool have = !RAGGED || lane + FX_WAVE * i < n;
+                const bool slow = have && fabsf(q - rintf(q)) < margin;
+                if (have)
+                    atomicAdd(&my_hist[(int)q], 1u);
                 const unsigned long long mask = __builtin_amdgcn_ballot_w64(slow);
                 if (mask && !redo) {
                     if (n_slow > SLOW_CAP)
@@ -1575,7 +1635,27 @@ int launch_full_sets(const PcaArgs &A, hipStream_t s)
     PcaArgs R = A;
     R.set_ids = A.redo_list;
     R.n_sets_dev = A.redo_count;
-    hipLaunchKernelGGL((pca_sets_redo_kernel<PPL, NW>), dim3((unsigned)(blocks < 256 ? blocks : 256)), dim3(FX_WAVE * NW), 0, s, R);
+    hipLaunchKernelGGL((pca_sets_redo_kernel<PPL, NW>), dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(FX_WAVE * NW), 0, s, R);
+    FX_HIP_CHECK(hipGetLastError());
+    return FX_OK;
+}
+
+// Sets of up to 64 * PPL points of any layout (set lists, CSR offsets, 2-D, unaligned): the ragged variant of the
+// full-set kernel; A.redo_list / A.redo_count take the sets left over.
+template <int PPL>
+int launch_ragged_sets(const PcaArgs &A, hipStream_t s)
+{
+    constexpr int NW = FX_PCA_NW;
+    auto k = A.normalize ? pca_sets_full_kernel<PPL, NW, true, true> : pca_sets_full_kernel<PPL, NW, false, true>;
+    const int64_t blocks = (A.n_sets + NW - 1) / NW;
+    FX_REQUIRE(blocks <= 0x7fffffffLL, "fx_pca_batch_f32: too many sets for one launch");
+    FX_REQUIRE(A.redo_list && A.redo_count, "fx_pca_batch_f32: no list for the sets to redo");
+    FX_HIP_CHECK(hipMemsetAsync(A.redo_count, 0, sizeof(int32_t), s));
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(FX_WAVE * NW), 0, s, A, 0.0, 0.0, 1.0 / (double)A.n_bins);
+    PcaArgs R = A;
+    R.set_ids = A.redo_list;
+    R.n_sets_dev = A.redo_count;
+    hipLaunchKernelGGL((pca_sets_redo_kernel<PPL, NW, true>), dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(FX_WAVE * NW), 0, s, R);
     FX_HIP_CHECK(hipGetLastError());
     return FX_OK;
 }
@@ -1593,7 +1673,7 @@ int launch_quad_sets(const PcaArgs &A, hipStream_t s)
     PcaArgs R = A;
     R.set_ids = A.redo_list;
     R.n_sets_dev = A.redo_count;
-    hipLaunchKernelGGL((pca_sets_redo_kernel<4, NW, true>), dim3((unsigned)(blocks < 256 ? blocks : 256)), dim3(FX_WAVE * NW), 0, s, R);
+    hipLaunchKernelGGL((pca_sets_redo_kernel<4, NW, true>), dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(FX_WAVE * NW), 0, s, R);
     FX_HIP_CHECK(hipGetLastError());
     return FX_OK;
 }
@@ -1609,6 +1689,8 @@ int launch_reg_sets(const PcaArgs &A, int64_t max_points, bool ragged, hipStream
         if (max_points == 512)
             return launch_full_sets<8>(A, s);
     }
+    if (A.redo_list)   // (without a redo list: the kernels that handle every set themselves)
+        return max_points <= 512 ? launch_ragged_sets<8>(A, s) : launch_ragged_sets<16>(A, s);
     const int64_t blocks = (A.n_sets + NW - 1) / NW;
     FX_REQUIRE(blocks <= 0x7fffffffLL, "fx_pca_batch_f32: too many sets for one launch");
     const dim3 grid((unsigned)blocks), block(FX_WAVE * NW);
@@ -1634,7 +1716,9 @@ int launch_reg_sets(const PcaArgs &A, int64_t max_points, bool ragged, hipStream
 int launch_small_sets(const PcaArgs &A, int64_t max_points, hipStream_t s)
 {
     if (max_points > REG_SET_MAX_POINTS && max_points <= 2 * REG_SET_MAX_POINTS) {
-        // sets of 1025..2048 points: the register kernel with 32 points per lane
+        // sets of 1025..2048 points: the register kernels with 32 points per lane
+        if (A.redo_list)
+            return launch_ragged_sets<32>(A, s);
         constexpr int NW = FX_PCA_NW;
         const int64_t blocks = (A.n_sets + NW - 1) / NW;
         FX_REQUIRE(blocks <= 0x7fffffffLL, "fx_pca_batch_f32: too many sets for one launch");
@@ -1883,6 +1967,8 @@ int launch_ragged_on_device(const PcaArgs &A, int64_t B, int64_t total, FxCallGu
         S.set_ids = L.reg_ids;
         S.n_sets = B;
         S.n_sets_dev = L.counts + 0;
+        S.redo_count = redo;          // (the launches run one after the other: they share the list)
+        S.redo_list = redo + 64;
         rc = launch_reg_sets(S, REG_SET_MAX_POINTS, true, s);
     }
     if (rc == FX_OK) {
@@ -1890,6 +1976,8 @@ int launch_ragged_on_device(const PcaArgs &A, int64_t B, int64_t total, FxCallGu
         S.set_ids = L.lds_ids;
         S.n_sets = B;
         S.n_sets_dev = L.counts + 1;
+        S.redo_count = redo;
+        S.redo_list = redo + 64;
         rc = launch_small_sets(S, WAVE_SET_MAX_POINTS, s);
     }
     if (rc != FX_OK || max_clouds == 0)
@@ -1945,7 +2033,7 @@ extern "C" int fx_pca_batch_f32(const float *d_pts, const int64_t *d_offsets, in
 
     if (!d_offsets) {
         const bool reg_ok = N >= 3 && N <= REG_SET_MAX_POINTS;
-        if (reg_ok && (N <= QUAD_MAX_POINTS || (dims == 3 && (N == 512 || N == 1024) && (uintptr_t)d_pts % 16 == 0))) {
+        if (N >= 3 && N <= WAVE_SET_MAX_POINTS) {
             // pca_sets_full_kernel's list of sets for pca_sets_redo_kernel
             int32_t *redo = (int32_t *)guard.scratch(((size_t)B + 64) * sizeof(int32_t), 0);
             if (!redo)
