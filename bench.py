@@ -358,9 +358,8 @@ def main(argv=None):
             feats = hu2d.hu_from_clouds_device(flat, cloud_off, 12, 224, preprocess_crop=True, use_silhouette=True)
             first_ms.append(0.0)
         elif kind == "sil+hu":
-            masks = eng.silhouette_batch(data, 224, 0.05, True)["mask"]
-            first_ms.append(eng.profile_last_ms())   # the Hu launch below overwrites the event pair
-            feats = eng.hu_batch(masks)["hulog7"]
+            feats = eng.silhouette_hu_batch(data, 224, 0.05, True)["hulog7"]   # Hu summed from the silhouette on chip
+            first_ms.append(eng.profile_last_ms())
         elif kind == "tail":
             hu = eng.hu_batch(data, thresh=127, on_value=255)["hulog7"] if units else torch.empty((0, 7), device=dev)
             first_ms.append(eng.profile_last_ms() if units else 0.0)

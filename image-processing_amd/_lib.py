@@ -37,6 +37,8 @@ SIGNATURES = {
                                  c_void_p, c_void_p, c_void_p]),
     "fx_silhouette_batch_u8": (c_int, [c_void_p, c_i64, c_int, c_int, c_i64, c_i64, c_int, ctypes.c_double, c_int,
                                        c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "fx_silhouette_moments_batch_u8": (c_int, [c_void_p, c_i64, c_int, c_int, c_i64, c_i64, c_int, ctypes.c_double,
+                                               c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fx_gray_fit_batch_u8": (c_int, [c_void_p, c_i64, c_int, c_int, c_i64, c_i64, c_void_p, c_int, c_int, c_void_p,
                                      c_void_p]),
     "fx_center_scale": (c_int, [c_void_p, c_int, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p]),

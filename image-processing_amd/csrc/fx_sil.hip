@@ -53,6 +53,7 @@ struct SilArgs {
     int tr;           // output rows per blur tile
     int mode;         // FX_SIL_PIL or FX_SIL_OPENCV: which branch of the reference is reproduced
     int32_t *level;   // [B] Otsu level, written by sil_otsu_cv_kernel (OpenCV branch)
+    int64_t *partial; // [B][10][3] or null: raw moments of the 0 / 255 silhouette as 48-bit limbs
 };
 
 __device__ __forceinline__ uint32_t sil_tap(uint32_t l, uint32_t c, uint32_t r)
@@ -929,6 +930,7 @@ __global__ __launch_bounds__(FX_BLOCK, 5) void sil_mask_kernel(SilArgs A)
     uint16_t *const s_ytab = s_xtab + SIL_MAX_SIDE + 32;              // [SIL_MAX_SIDE]
     __shared__ int s_v[SV_N];
     __shared__ unsigned long long s_best, s_first;
+    __shared__ unsigned long long s_mom[10][8];
 #ifdef SIL_TIMING
     __shared__ unsigned long long s_tick[24];
 #endif
@@ -955,6 +957,8 @@ __global__ __launch_bounds__(FX_BLOCK, 5) void sil_mask_kernel(SilArgs A)
             s_best = 0ull;
             s_first = ~0ull;
         }
+        if (t < 80)
+            s_mom[t >> 3][t & 7] = 0ull;
         __syncthreads();
         SIL_TICK(0);
         constexpr bool cv = CV;
@@ -1608,10 +1612,74 @@ __global__ __launch_bounds__(FX_BLOCK, 5) void sil_mask_kernel(SilArgs A)
 
         }
         SIL_TICK(12);
-        // ---- centred paste on the res x res canvas
         const int px0 = (res - new_w) / 2, py0 = (res - new_h) / 2;
+        // ---- raw moments of the silhouette as the 0 / 255 image it is on the canvas (what cv2.moments sums over
+        // that image, reference :449): exact integers from the row runs of the bit mask.  Over a run of columns
+        // a .. b the column powers have closed sums; a run that crosses a word is taken piece by piece.
+        if (A.partial) {
+            // Per piece (at most 32 columns, columns below 512) everything fits 32 bits: s1 = sum x, six times
+            // sum x^2 (the division by six waits for the total), sum x^3 = s1 * (T(b) + T(a - 1)) with the
+            // triangular numbers T; the products with the row's powers go into 64-bit sums.
+            unsigned long long acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int wi = t; wi < nwS; wi += FX_BLOCK) {
+                const int y = sil_div(wi, GS.dv), w = wi - y * wcS;
+                uint32_t word = mK[y * wpr + w];
+                const uint32_t Y = (uint32_t)(y + py0), Y2 = Y * Y;
+                const unsigned long long Y3 = (unsigned long long)Y2 * Y;
+                uint32_t r0 = 0, r1 = 0;           // the row's pieces in this word: counts and sums of x
+                unsigned long long r2 = 0, r3 = 0; // 6 sum x^2, sum x^3
+                while (word) {
+                    const uint32_t low = word & (0u - word);
+                    const uint32_t seg = word & ~(word + low);  // the lowest stretch of ones
+                    const uint32_t a = (uint32_t)(px0 + 32 * w + __ffs((int)word) - 1), len = __popc(seg), bq = a + len - 1;
+                    word &= ~seg;
+                    const uint32_t tb = (bq * (bq + 1)) >> 1, ta = (a * (a - 1)) >> 1;   // T(b), T(a - 1)  (a = 0: 0)
+                    const uint32_t s1 = tb - ta;
+                    const uint32_t f2b = bq * (bq + 1) * (2 * bq + 1), f2a = a == 0 ? 0u : (a - 1) * a * (2 * a - 1);
+                    r0 += len;
+                    r1 += s1;
+                    r2 += f2b - f2a;
+                    r3 += (unsigned long long)s1 * (tb + ta);
+                }
+                if (r0) {
+                    acc[0] += r0;
+                    acc[1] += r1;
+                    acc[2] += (unsigned long long)Y * r0;
+                    acc[3] += r2;
+                    acc[4] += (unsigned long long)Y * r1;
+                    acc[5] += (unsigned long long)Y2 * r0;
+                    acc[6] += r3;
+                    acc[7] += Y * r2;
+                    acc[8] += (unsigned long long)Y2 * r1;
+                    acc[9] += Y3 * r0;
+                }
+            }
+            // eight copies per moment, lane l adding to copy l % 8: 64 lanes on one LDS word would take turns
+            if (acc[0]) {
+#pragma unroll
+                for (int k = 0; k < 10; k++)
+                    atomicAdd(&s_mom[k][t & 7], acc[k]);
+            }
+            __syncthreads();
+            if (t < 10) {
+                unsigned long long v = 0;
+#pragma unroll
+                for (int c = 0; c < 8; c++)
+                    v += s_mom[t][c];
+                if (t == 3 || t == 7)
+                    v /= 6ull;   // sums of x^2 were kept six-fold
+                v *= 255ull;     // pixel value 255; at most 255 * 512^2 * 511^3 < 2^63
+                int64_t *limb = A.partial + (b * 10 + t) * 3;
+                limb[0] = (int64_t)(v & ((1ull << 48) - 1ull));
+                limb[1] = (int64_t)(v >> 48);
+                limb[2] = 0;
+            }
+        }
+        // ---- centred paste on the res x res canvas
         uint8_t *out = A.mask + b * (int64_t)res * res;
-        if ((res & 15) == 0) {
+        if (!A.mask) {
+            // the caller wants the moments only
+        } else if ((res & 15) == 0) {
             const int cpr = res >> 4;
             for (int ci = t; ci < res * cpr; ci += FX_BLOCK) {
                 const int Y = sil_div(ci, dvP), X0 = (ci - Y * cpr) * 16;
@@ -1668,11 +1736,11 @@ __global__ __launch_bounds__(FX_BLOCK, 5) void sil_mask_kernel(SilArgs A)
 
 inline size_t sil_align(size_t v) { return (v + 255) & ~(size_t)255; }
 
-}  // namespace
-
-extern "C" int fx_silhouette_batch_u8(const uint8_t *d_img, int64_t B, int H, int W, int64_t pitch, int64_t stride,
-                                      int resolution, double crop_margin, int preprocess_crop, int min_size,
-                                      int mode, uint8_t *d_mask, int32_t *d_info, void *stream_)
+// The silhouette stage behind fx_silhouette_batch_u8 (masks) and fx_silhouette_moments_batch_u8 (raw moments of
+// the masks, masks optional).
+int sil_batch(const uint8_t *d_img, int64_t B, int H, int W, int64_t pitch, int64_t stride, int resolution,
+              double crop_margin, int preprocess_crop, int min_size, int mode, uint8_t *d_mask, int32_t *d_info,
+              int64_t *d_partial, void *stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     FX_REQUIRE(mode == FX_SIL_PIL || mode == FX_SIL_OPENCV, "fx_silhouette_batch_u8: mode %d (0 = PIL/scipy branch, "
@@ -1680,7 +1748,7 @@ extern "C" int fx_silhouette_batch_u8(const uint8_t *d_img, int64_t B, int H, in
     FX_REQUIRE(B >= 0, "fx_silhouette_batch_u8: B = %lld", (long long)B);
     if (B == 0)
         return FX_OK;
-    FX_REQUIRE(d_img && d_mask, "fx_silhouette_batch_u8: null image or mask pointer");
+    FX_REQUIRE(d_img && (d_mask || d_partial), "fx_silhouette_batch_u8: null image pointer, or no output");
     FX_REQUIRE(H >= 1 && W >= 1 && H <= SIL_MAX_SIDE && W <= SIL_MAX_SIDE,
                "fx_silhouette_batch_u8: views of %dx%d; supported up to %dx%d", H, W, SIL_MAX_SIDE, SIL_MAX_SIDE);
     FX_REQUIRE(resolution >= 1 && resolution <= SIL_MAX_SIDE, "fx_silhouette_batch_u8: resolution %d outside 1..%d",
@@ -1790,7 +1858,8 @@ extern "C" int fx_silhouette_batch_u8(const uint8_t *d_img, int64_t B, int H, in
         const int64_t nb = B - b0 < chunk ? B - b0 : chunk;
         A.img = d_img + b0 * stride;
         A.B = nb;
-        A.mask = d_mask + b0 * (int64_t)resolution * resolution;
+        A.mask = d_mask ? d_mask + b0 * (int64_t)resolution * resolution : nullptr;
+        A.partial = d_partial ? d_partial + b0 * 30 : nullptr;
         A.info = d_info ? d_info + b0 * 8 : nullptr;
         FX_HIP_CHECK(hipMemsetAsync(A.hist, 0, (size_t)nb * 256 * sizeof(uint32_t), stream));
         const dim3 bgrid((unsigned)((H + tr - 1) / tr), (unsigned)nb);
@@ -1818,6 +1887,27 @@ extern "C" int fx_silhouette_batch_u8(const uint8_t *d_img, int64_t B, int H, in
         FX_HIP_CHECK(hipGetLastError());
     }
     return FX_OK;
+}
+
+}  // namespace
+
+extern "C" int fx_silhouette_batch_u8(const uint8_t *d_img, int64_t B, int H, int W, int64_t pitch, int64_t stride,
+                                      int resolution, double crop_margin, int preprocess_crop, int min_size,
+                                      int mode, uint8_t *d_mask, int32_t *d_info, void *stream)
+{
+    FX_REQUIRE(B <= 0 || d_mask, "fx_silhouette_batch_u8: null image or mask pointer");
+    return sil_batch(d_img, B, H, W, pitch, stride, resolution, crop_margin, preprocess_crop, min_size, mode, d_mask,
+                     d_info, nullptr, stream);
+}
+
+extern "C" int fx_silhouette_moments_batch_u8(const uint8_t *d_img, int64_t B, int H, int W, int64_t pitch,
+                                              int64_t stride, int resolution, double crop_margin, int preprocess_crop,
+                                              int min_size, int mode, uint8_t *d_mask, int32_t *d_info,
+                                              int64_t *d_partial, void *stream)
+{
+    FX_REQUIRE(B <= 0 || d_partial, "fx_silhouette_moments_batch_u8: null moments pointer");
+    return sil_batch(d_img, B, H, W, pitch, stride, resolution, crop_margin, preprocess_crop, min_size, mode, d_mask,
+                     d_info, d_partial, stream);
 }
 
 // ---------------------------------------------------------------------------

@@ -167,6 +167,40 @@ def silhouette_batch(images: torch.Tensor, resolution: int = 224, crop_margin: f
     return out
 
 
+def silhouette_hu_batch(images: torch.Tensor, resolution: int = 224, crop_margin: float = 0.05,
+                        preprocess_crop: bool = True, min_size: int = -1, *, mask: bool = False, info: bool = False,
+                        backend: str = "opencv", moments: bool = False, hu: bool = False) -> dict:
+    """silhouette_batch followed by hu_batch on the silhouettes, in one pass: the raw moments are summed from the
+    bit mask while it is on chip, so the silhouettes are neither re-read nor (unless mask=True) written.
+    {"hulog7"} [B, 7] float32 -- bit for bit hu_batch(silhouette_batch(...)["mask"])["hulog7"] -- and on request
+    "moments24", "hu7", "mask", "info"."""
+    if backend not in SIL_BACKENDS:
+        raise ValueError(f"backend must be 'opencv' or 'pil', got {backend!r}")
+    _require_cuda(images, "images")
+    if images.dtype != torch.uint8 or images.dim() != 3:
+        raise ValueError(f"images must be uint8 [B, H, W], got {images.dtype} {tuple(images.shape)}")
+    if images.stride(2) != 1 and images.shape[2] > 1:
+        raise ValueError("images must have a unit stride along the row")
+    stream = _enter(images.device)
+    B, H, W = images.shape
+    res = int(resolution)
+    extra = {}
+    if mask:
+        extra["mask"] = torch.empty((B, res, res), dtype=torch.uint8, device=images.device)
+    if info:
+        extra["info"] = torch.empty((B, 8), dtype=torch.int32, device=images.device)
+    partial = torch.empty((B, 10, 3), dtype=torch.int64, device=images.device)
+    if B:
+        pitch = images.stride(1) if H > 1 else W
+        stride = images.stride(0) if B > 1 else pitch * H
+        _lib.call("fx_silhouette_moments_batch_u8", images.data_ptr(), B, H, W, pitch, stride, res, float(crop_margin),
+                  int(bool(preprocess_crop)), int(min_size), SIL_BACKENDS[backend], _ptr(extra.get("mask")),
+                  _ptr(extra.get("info")), partial.data_ptr(), stream)
+    out = hu_from_partial(partial, moments=moments, hu=hu)
+    out.update(extra)
+    return out
+
+
 def gray_fit_batch(images: torch.Tensor, info: Optional[torch.Tensor] = None, resolution: int = 224,
                    bg_value: int = 255) -> torch.Tensor:
     """Bicubic aspect-preserving fit of each view's crop rectangle (columns 2..5

@@ -163,15 +163,19 @@ def hu_from_clouds_device(points, offsets, views: int = 12, resolution: int = 22
                                                 camera_radius_factor, seed)
     B = rendered.shape[0]
     raw = rendered.reshape(B * views, resolution, resolution)
-    if use_silhouette or preprocess_crop:
-        sil = engine.silhouette_batch(raw, resolution, crop_margin, preprocess_crop, info=not use_silhouette,
-                                      backend=backend or SILHOUETTE_BACKEND)
-        target = sil["mask"] if use_silhouette else engine.gray_fit_batch(raw, sil["info"], resolution,
-                                                                          255 if bg_color == "white" else 0)
+    if use_silhouette:
+        # Hu of the silhouettes: moments summed while a silhouette is on chip, the silhouettes are not written
+        rows = engine.silhouette_hu_batch(raw, resolution, crop_margin, preprocess_crop,
+                                          backend=backend or SILHOUETTE_BACKEND)["hulog7"]
     else:
-        # the gray view itself is measured: the reference computes a silhouette here too and drops it (:372-397, :626)
-        target = engine.gray_fit_batch(raw, None, resolution, 255 if bg_color == "white" else 0)
-    rows = engine.hu_batch(target)["hulog7"]
+        if preprocess_crop:
+            sil = engine.silhouette_batch(raw, resolution, crop_margin, preprocess_crop, info=True,
+                                          backend=backend or SILHOUETTE_BACKEND)
+            target = engine.gray_fit_batch(raw, sil["info"], resolution, 255 if bg_color == "white" else 0)
+        else:
+            # the gray view itself is measured: the reference computes a silhouette here too and drops it (:372-397, :626)
+            target = engine.gray_fit_batch(raw, None, resolution, 255 if bg_color == "white" else 0)
+        rows = engine.hu_batch(target)["hulog7"]
     off = torch.arange(B + 1, dtype=torch.int64, device=points.device) * views
     out = engine.hu_groupstat(rows, off)
     return (out, rendered) if return_views else out
@@ -346,16 +350,18 @@ def finish_samples(decoded: Dict[str, Any]) -> List[Dict[str, Any]]:
                     if idx:
                         parts.append(ingest.stack_to_device([views[i] for i in idx], dev, decoded["workers"]))
                     raw = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
-                    if use_silhouette or preprocess_crop:
-                        sil = engine.silhouette_batch(raw, resolution, crop_margin, preprocess_crop,
-                                                      info=not use_silhouette, backend=backend)
                     if use_silhouette:
-                        target = sil["mask"]
+                        # moments summed while a silhouette is on chip; the silhouettes are not written
+                        got = engine.silhouette_hu_batch(raw, resolution, crop_margin, preprocess_crop,
+                                                         backend=backend)["hulog7"]
                     else:
                         # without a crop the gray view does not depend on the silhouette (reference :372-374)
+                        sil = engine.silhouette_batch(raw, resolution, crop_margin, preprocess_crop, info=True,
+                                                      backend=backend) if preprocess_crop else None
                         target = engine.gray_fit_batch(raw, sil["info"] if preprocess_crop else None, resolution,
                                                        255 if bg_color == "white" else 0)
-                    rows_all[torch.from_numpy(where).to(dev)] = engine.hu_batch(target)["hulog7"]
+                        got = engine.hu_batch(target)["hulog7"]
+                    rows_all[torch.from_numpy(where).to(dev)] = got
                 except Exception as e:
                     # the reference logs a view that fails and goes on with the sample's other views (:629-636)
                     usable[where] = False

@@ -216,6 +216,25 @@ int fx_silhouette_batch_u8(const uint8_t *d_img, int64_t B, int H, int W,
                            int mode, uint8_t *d_mask, int32_t *d_info, void *stream);
 
 /*
+ * fx_silhouette_batch_u8 fused with the moment sums of the call that follows
+ * it in the reference, compute_hu_from_mask / cv2.moments on the silhouette
+ * (src/features/extract_2d_hu.py:443-470): d_partial int64 [B, 10, 3] receives
+ * the exact integer raw moments m00, m10, m01, m20, m11, m02, m30, m21, m12, m03
+ * of the 0 / 255 silhouette on its resolution x resolution canvas, as the
+ * 48-bit limbs fx_hu_from_partial takes, summed from the row runs of the bit
+ * mask while it is still on chip.  fx_hu_from_partial(d_partial, ...) then gives
+ * bit for bit what fx_hu_batch_u8 gives on d_mask.  d_mask may be NULL (the
+ * silhouettes are then never written: the reference keeps them only for its
+ * previews); the other arguments are those of fx_silhouette_batch_u8.
+ */
+int fx_silhouette_moments_batch_u8(const uint8_t *d_img, int64_t B, int H, int W,
+                                   int64_t pitch, int64_t stride, int resolution,
+                                   double crop_margin, int preprocess_crop,
+                                   int min_size, int mode, uint8_t *d_mask,
+                                   int32_t *d_info, int64_t *d_partial,
+                                   void *stream);
+
+/*
  * Gray half of preprocess_image: pad_and_resize, src/features/extract_2d_hu.py
  * :224-240 (PIL ImageOps.contain with its default bicubic filter, then a
  * centred paste on a canvas of the background colour), applied to the crop

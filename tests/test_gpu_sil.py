@@ -257,3 +257,32 @@ def test_preprocess_image_signature(gpu, oracle, hu_panels):
         np.testing.assert_array_equal(mask, wmask)
     np.testing.assert_array_equal(hu.pad_and_resize(img[10:200, 30:180], 96, "black"),
                                   oracle.pad_and_resize(img[10:200, 30:180], 96, "black"))
+
+
+@pytest.mark.parametrize("h,w,res,crop", [(224, 224, 224, True), (200, 152, 160, True), (97, 130, 100, False),
+                                          (512, 512, 224, True), (64, 64, 512, True), (224, 224, 37, True)])
+def test_moments_summed_on_chip_equal_hu_of_the_masks(gpu, backend, h, w, res, crop):
+    """The fused call (moments from the bit mask's row runs) gives bit for bit what the two calls give, with and
+    without the silhouettes written; empty, full and single-pixel silhouettes included."""
+    eng = pkg("engine")
+    rng = np.random.default_rng(h * 1000 + w + res)
+    imgs = np.stack([gray_scene(rng, h, w, dark_object=bool(k % 2), blobs=1 + k % 5) for k in range(14)])
+    imgs[0] = 200                      # flat view
+    imgs[1] = 0
+    imgs[2] = 255
+    imgs[2, h // 2, w // 2] = 0        # a single dark pixel
+    d = torch.from_numpy(imgs).to(gpu)
+    two = eng.silhouette_batch(d, res, 0.05, crop, info=True, backend=backend)
+    want = eng.hu_batch(two["mask"], moments=True, hu=True)
+    fused = eng.silhouette_hu_batch(d, res, 0.05, crop, mask=True, info=True, backend=backend, moments=True, hu=True)
+    lean = eng.silhouette_hu_batch(d, res, 0.05, crop, backend=backend)
+    torch.cuda.synchronize()
+    assert torch.equal(fused["mask"], two["mask"]) and torch.equal(fused["info"], two["info"])
+    for key in ("moments24", "hu7", "hulog7"):
+        a, b = fused[key].cpu().numpy(), want[key].cpu().numpy()
+        assert np.array_equal(a, b, equal_nan=True), key
+    assert np.array_equal(lean["hulog7"].cpu().numpy(), want["hulog7"].cpu().numpy(), equal_nan=True)
+    assert set(lean) == {"hulog7"}
+    # an empty batch
+    none = eng.silhouette_hu_batch(d[:0], res, 0.05, crop, backend=backend)
+    assert tuple(none["hulog7"].shape) == (0, 7)
