@@ -1148,26 +1148,6 @@ __global__ __launch_bounds__(FX_BLOCK, 5) void sil_mask_kernel(SilArgs A)
             // otherwise the mask is labelled as it is, and it has no hole exactly when it has E components.
             SIL_TICK(14);
             const int wcV = (W + 32) >> 5;  // corners x = 0 .. W
-            {
-                int e4 = 0;
-                for (int vi = t; vi < (H + 1) * wcV; vi += FX_BLOCK) {
-                    const int vy = sil_div(vi, dvV), w = vi - vy * wcV;
-                    const uint32_t *ru = mA + (vy - 1) * wpr, *rd = mA + vy * wpr;
-                    const uint32_t up = vy > 0 && w < wcH ? ru[w] : 0u, upp = vy > 0 && w > 0 ? ru[w - 1] : 0u;
-                    const uint32_t dn = vy < H && w < wcH ? rd[w] : 0u, dnp = vy < H && w > 0 ? rd[w - 1] : 0u;
-                    const uint32_t ca = (up << 1) | (upp >> 31), cb = up, cc = (dn << 1) | (dnp >> 31), cd = dn;
-                    const uint32_t odd = ca ^ cb ^ cc ^ cd;
-                    const uint32_t three = odd & ((ca & cb) | (cc & cd));
-                    const uint32_t diag = (ca & cd & ~(cb | cc)) | (cb & cc & ~(ca | cd));
-                    e4 += __popc(odd & ~three) - __popc(three) - 2 * __popc(diag);
-                }
-#pragma unroll
-                for (int o = FX_WAVE / 2; o > 0; o >>= 1)
-                    e4 += __shfl_xor(e4, o, FX_WAVE);
-                if (fx_lane() == 0 && e4)
-                    atomicAdd(&s_v[SV_HOLES4], e4);
-            }
-            __syncthreads();
             // First the mask is labelled as it is.  Without holes (as many components as the Euler number) its
             // components are the external contours.  With holes the corner sums below give a component's outer area
             // minus its holes' areas: the component with the largest such value is still the winner if it beats
@@ -1209,6 +1189,27 @@ __global__ __launch_bounds__(FX_BLOCK, 5) void sil_mask_kernel(SilArgs A)
                     sil_box_reduce(mnx, mny, mxx, mxy, s_v);
                     return false;
                 }
+                // several components: the Euler number, to know whether any of them has a hole
+                {
+                    int e4 = 0;
+                    for (int vi = t; vi < (H + 1) * wcV; vi += FX_BLOCK) {
+                        const int vy = sil_div(vi, dvV), w = vi - vy * wcV;
+                        const uint32_t *ru = mA + (vy - 1) * wpr, *rd = mA + vy * wpr;
+                        const uint32_t up = vy > 0 && w < wcH ? ru[w] : 0u, upp = vy > 0 && w > 0 ? ru[w - 1] : 0u;
+                        const uint32_t dn = vy < H && w < wcH ? rd[w] : 0u, dnp = vy < H && w > 0 ? rd[w - 1] : 0u;
+                        const uint32_t ca = (up << 1) | (upp >> 31), cb = up, cc = (dn << 1) | (dnp >> 31), cd = dn;
+                        const uint32_t odd = ca ^ cb ^ cc ^ cd;
+                        const uint32_t three = odd & ((ca & cb) | (cc & cd));
+                        const uint32_t diag = (ca & cd & ~(cb | cc)) | (cb & cc & ~(ca | cd));
+                        e4 += __popc(odd & ~three) - __popc(three) - 2 * __popc(diag);
+                    }
+#pragma unroll
+                    for (int o = FX_WAVE / 2; o > 0; o >>= 1)
+                        e4 += __shfl_xor(e4, o, FX_WAVE);
+                    if (fx_lane() == 0 && e4)
+                        atomicAdd(&s_v[SV_HOLES4], e4);
+                }
+                __syncthreads();
             }
             const bool holes = first && s_v[SV_HOLES4] != 0;
             SIL_TICK(15);
