@@ -2,14 +2,24 @@
 // src/features/extract_3d_pca_features.py:59-145, inputs widened from the
 // float32 file contents as load_sample :48-56 does).
 //
-// Small sets (the pipeline's 1024-point clouds): one wavefront per set.  The
-// set is copied once from HBM into the wave's LDS slab with coalesced 16 B
-// loads; centring, covariance, eigen-decomposition, |projection| maximum and
-// histogram all run out of LDS, so HBM is read exactly once.  No block
-// barriers: waves are independent.
+// Sets of up to 2048 points are read from HBM exactly once and stay in
+// registers for every pass:
+//   * pca_sets_full_kernel    a wave per set (8 / 16 / 32 points per lane): the
+//                             aligned 512- and 1024-point batches of the
+//                             pipeline, and (RAGGED) every other layout of 257
+//                             to 2048 points -- set lists, CSR offsets, 2-D;
+//   * pca_sets_quad_kernel    sets of up to 256 points, four to a wave;
+//   * pca_sets_redo_kernel    the few sets those hand on (pca_sets_reg_body:
+//                             float64 decisions throughout);
+//   * pca_sets_wave_kernel    a set staged in the wave's LDS slab (batches of
+//                             fewer than three points per set: NaN rows).
+// What is per set and serial (mean, covariance, eigen-solve, the nine scalars)
+// is computed by one wave per block, a lane per set, or by the 16 lanes of a
+// set's row.
 //
-// Large clouds: one block per cloud streaming from global memory in four
-// passes (sum, centred second moments, projection maximum, histogram).
+// Large clouds: cut into chunks of 16384 points, one launch per pass (sum,
+// centred second moments, projection maximum, histogram) with a block per
+// chunk; a CSR batch is sorted into the lists of the kernels on the device.
 #include "fx_common.h"
 #include "fx_eig.h"
 #include <stdlib.h>
