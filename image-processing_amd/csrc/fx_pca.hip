@@ -1759,31 +1759,46 @@ struct RaggedLists {
     int64_t max_clouds, max_chunks;
 };
 
-__global__ __launch_bounds__(FX_BLOCK) void pca_classify_kernel(PcaArgs A, RaggedLists L, int64_t B, int64_t reg_max)
+constexpr int CLASSIFY_THREADS = 1024, CLASSIFY_WAVES = CLASSIFY_THREADS / FX_WAVE;
+__global__ __launch_bounds__(CLASSIFY_THREADS) void pca_classify_kernel(PcaArgs A, RaggedLists L, int64_t B, int64_t reg_max)
 {
-    const int64_t b = (int64_t)blockIdx.x * FX_BLOCK + threadIdx.x;
+    // one atomic per block and list (thousands of waves adding to the same four counters take turns at the L2);
+    // within a block the sets keep their order
+    __shared__ int wave_cnt[CLASSIFY_WAVES][4];
+    __shared__ int block_base[4];
+    const int64_t b = (int64_t)blockIdx.x * CLASSIFY_THREADS + threadIdx.x;
     int cls = -1;
     if (b < B) {
         // a set of fewer than three points (or with decreasing offsets) gets its NaN row from the set kernels
         const int64_t n = A.offsets[b + 1] - A.offsets[b];
         cls = n <= QUAD_MAX_POINTS ? 3 : n <= reg_max ? 0 : n <= WAVE_SET_MAX_POINTS ? 1 : 2;
     }
-    const int lane = fx_lane();
+    const int lane = fx_lane(), wave = fx_wave();
+    unsigned long long mine = 0ull;   // the lanes of this wave in the same list as this lane
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(cls == c);
-        if (!mask)
-            continue;
-        int base = 0;
-        if (lane == __builtin_ctzll(mask))
-            base = atomicAdd(&L.counts[c == 3 ? 4 : c], (int)__builtin_popcountll(mask));   // one atomic per wave and list
-        base = __builtin_amdgcn_readlane(base, __builtin_ctzll(mask));
-        if (cls == c) {
-            const int pos = base + (int)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
-            int32_t *list = c == 0 ? L.reg_ids : c == 1 ? L.lds_ids : c == 2 ? L.cloud_ids : L.quad_ids;
-            if (c != 2 || pos < L.max_clouds)
-                list[pos] = (int32_t)b;
-        }
+        if (lane == 0)
+            wave_cnt[wave][c] = (int)__builtin_popcountll(mask);
+        if (cls == c)
+            mine = mask;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int c = threadIdx.x;
+        int total = 0;
+        for (int w = 0; w < CLASSIFY_WAVES; w++)
+            total += wave_cnt[w][c];
+        block_base[c] = total ? atomicAdd(&L.counts[c == 3 ? 4 : c], total) : 0;
+    }
+    __syncthreads();
+    if (cls >= 0) {
+        int pos = block_base[cls] + (int)__builtin_popcountll(mine & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; w++)
+            pos += wave_cnt[w][cls];
+        int32_t *list = cls == 0 ? L.reg_ids : cls == 1 ? L.lds_ids : cls == 2 ? L.cloud_ids : L.quad_ids;
+        if (cls != 2 || pos < L.max_clouds)
+            list[pos] = (int32_t)b;
     }
 }
 
@@ -1958,7 +1973,7 @@ int launch_ragged_on_device(const PcaArgs &A, int64_t B, int64_t total, FxCallGu
 
     FX_HIP_CHECK(hipMemsetAsync(L.counts, 0, counts_bytes, s));
     const int64_t reg_max = REG_SET_MAX_POINTS;
-    hipLaunchKernelGGL(pca_classify_kernel, dim3((unsigned)((B + FX_BLOCK - 1) / FX_BLOCK)), dim3(FX_BLOCK), 0, s, A, L, B,
+    hipLaunchKernelGGL(pca_classify_kernel, dim3((unsigned)((B + CLASSIFY_THREADS - 1) / CLASSIFY_THREADS)), dim3(CLASSIFY_THREADS), 0, s, A, L, B,
                        reg_max);
     FX_HIP_CHECK(hipGetLastError());
     FxProfileScope prof(s);
