@@ -267,3 +267,25 @@ def test_small_sets_four_per_wave(gpu, oracle, N, dims, normalize, nb):
             got[7] = ref_out[7]
         ties += compare_set(got, eig[b], ref_out, ref_eig, N, strict_rel=not degenerate)
     assert ties <= 3
+
+
+@pytest.mark.parametrize("N", [64, 256, 700, 1024, 1500])
+def test_non_finite_points_do_not_disturb_their_neighbours(gpu, oracle, N):
+    """A NaN or an infinity in one set (the reference's eigh raises or returns NaN for it): the call returns, that
+    set's row is not finite, the other sets of the batch are what they are without it."""
+    import torch
+    eng = pkg("engine")
+    rng = np.random.default_rng(N)
+    pts = (rng.normal(size=(12, N, 3)) * np.array([1.0, 0.5, 0.2])).astype(np.float32)
+    clean = eng.pca_batch(torch.from_numpy(pts).to(gpu), None, 8, False)["out"].cpu().numpy()
+    bad = pts.copy()
+    bad[3, N // 2, 1] = np.nan
+    bad[7, 0, 0] = np.inf
+    bad[9, N - 1, 2] = -np.inf
+    out = eng.pca_batch(torch.from_numpy(bad).to(gpu), None, 8, False)["out"].cpu().numpy()
+    torch.cuda.synchronize()
+    for b in range(12):
+        if b in (3, 7, 9):
+            assert not np.isfinite(out[b]).all()
+        else:
+            np.testing.assert_array_equal(out[b], clean[b])
