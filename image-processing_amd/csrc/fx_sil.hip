@@ -33,6 +33,21 @@ constexpr int SIL_MAX_GRID = 1024;  // mask kernel grid when the occupancy query
 constexpr uint32_t SIL_WW = 11184811u;
 constexpr uint32_t SIL_FW = 2796202u;
 
+// Division of small non-negative numbers (below 2^23) by a block-uniform divisor of at most 512 that is not
+// known at compile time: a multiplication by ceil(2^32 / d) instead of the twenty-odd instructions of a
+// 32-bit division, which the word loops below would otherwise pay once per mask word and pass.
+struct SilDiv {
+    uint32_t d, magic;
+};
+__device__ __forceinline__ SilDiv sil_div_make(int d)
+{
+    SilDiv v;
+    v.d = (uint32_t)d;
+    v.magic = d > 1 ? 0xFFFFFFFFu / (uint32_t)d + 1u : 0u;
+    return v;
+}
+__device__ __forceinline__ int sil_div(int n, SilDiv v) { return v.d > 1 ? (int)__umulhi((uint32_t)n, v.magic) : n; }
+
 struct SilArgs {
     const uint8_t *img;
     int64_t B;
@@ -112,8 +127,9 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_blur_kernel(SilArgs A)
     const int ihi = A.H - 1 - r0 + SIL_HALO < trows - 1 ? A.H - 1 - r0 + SIL_HALO : trows - 1;
 
     // three passes along x: 16 pixels + 3 on each side in registers
+    const SilDiv dv_cpr = sil_div_make(cpr);
     for (int it = threadIdx.x; it < trows * cpr; it += FX_BLOCK) {
-        const int i = it / cpr, c = it - i * cpr;
+        const int i = sil_div(it, dv_cpr), c = it - i * cpr;
         if (i < ilo || i > ihi)
             continue;
         const uint8_t *row = src + (int64_t)(r0 - SIL_HALO + i) * A.pitch;
@@ -284,40 +300,78 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_blur_cv_kernel(SilArgs A)
     const int half_row = Wp >> 1;
 
     // along x: 16 pixels + 2 on each side in registers; tile row i is image row reflect(r0 - 2 + i)
-    for (int it = threadIdx.x; it < trows * cpr; it += FX_BLOCK) {
-        const int i = it / cpr, c = it - i * cpr;
+    const SilDiv dv_cpr = sil_div_make(cpr);
+    if (ALIGNED) {   // W is a multiple of 16 (so at least 16) and rows are 16-byte aligned
+        // A block lives for a few microseconds, most of them waiting: the loads of two rounds of the loop are
+        // issued together, so that a block waits for global memory once instead of twice.
+        constexpr int XR = 2;
+        for (int it0 = threadIdx.x; it0 < trows * cpr; it0 += XR * FX_BLOCK) {
+            uint4 mm[XR];
+            uint32_t ll[XR], rr[XR];
+            int ti[XR], tc[XR];
+#pragma unroll
+            for (int u = 0; u < XR; u++) {
+                const int it = it0 + u * FX_BLOCK;
+                mm[u] = make_uint4(0u, 0u, 0u, 0u);
+                ll[u] = rr[u] = 0u;
+                ti[u] = -1;
+                tc[u] = 0;
+                if (it < trows * cpr) {
+                    const int i = sil_div(it, dv_cpr), c = it - i * cpr;
+                    const uint8_t *row = src + (int64_t)sil_refl101(r0 - SIL_CV_HALO + i, H) * A.pitch;
+                    const int x0 = c * 16;
+                    ti[u] = i;
+                    tc[u] = c;
+                    mm[u] = *(const uint4 *)(row + x0);
+                    if (x0 > 0)
+                        ll[u] = *(const uint32_t *)(row + x0 - 4);
+                    if (x0 + 16 < W)
+                        rr[u] = *(const uint32_t *)(row + x0 + 16);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < XR; u++) {
+                if (ti[u] < 0)
+                    continue;
+                const int i = ti[u], c = tc[u], x0 = c * 16;
+                uint4 *dst_lo = (uint4 *)(tile + (size_t)i * Wp + 8 * c);
+                uint4 *dst_hi = (uint4 *)(tile + (size_t)i * Wp + half_row + 8 * c);
+                // Pairs of neighbouring pixels as two 16-bit fields of a word, P[j] = (pixel j - 2, pixel j - 1)
+                // counted from the chunk's first pixel: one byte permute each.  A sum of the five taps is at most
+                // 255 * 16, so plain 32-bit arithmetic on such words never carries from one field into the other
+                // and two output pixels cost four instructions.
+                const uint4 m = mm[u];
+                // left word: bytes 2, 3 = pixels x0 - 2, x0 - 1 (reflected at the row's start: pixels 2, 1)
+                const uint32_t l = x0 > 0 ? ll[u] : __builtin_amdgcn_perm(0u, m.x, 0x01020c0cu);
+                // right word: bytes 0, 1 = pixels x0 + 16, x0 + 17 (reflected at the row's end: pixels 14, 13)
+                const uint32_t r = x0 + 16 < W ? rr[u] : __builtin_amdgcn_perm(0u, m.w, 0x0c0c0102u);
+                const uint32_t wd[6] = {l, m.x, m.y, m.z, m.w, r};
+                uint32_t P[19];
+#pragma unroll
+                for (int j = 0; j < 19; j++) {
+                    // first pixel of the pair is byte (j + 2) & 3 of word (j + 2) >> 2
+                    const int w0 = (j + 2) >> 2, b0 = (j + 2) & 3;
+                    P[j] = b0 == 0   ? __builtin_amdgcn_perm(0u, wd[w0], 0x0c010c00u)
+                           : b0 == 1 ? __builtin_amdgcn_perm(0u, wd[w0], 0x0c020c01u)
+                           : b0 == 2 ? __builtin_amdgcn_perm(0u, wd[w0], 0x0c030c02u)
+                                     : __builtin_amdgcn_perm(wd[w0 + 1], wd[w0], 0x0c040c03u);
+                }
+                uint32_t o[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    o[k] = sil_taps5(P[2 * k], P[2 * k + 1], P[2 * k + 2], P[2 * k + 3], P[2 * k + 4], 0u);
+                *dst_lo = make_uint4(o[0], o[1], o[2], o[3]);
+                *dst_hi = make_uint4(o[4], o[5], o[6], o[7]);
+            }
+        }
+    }
+    for (int it = threadIdx.x; !ALIGNED && it < trows * cpr; it += FX_BLOCK) {
+        const int i = sil_div(it, dv_cpr), c = it - i * cpr;
         const uint8_t *row = src + (int64_t)sil_refl101(r0 - SIL_CV_HALO + i, H) * A.pitch;
         const int x0 = c * 16;
         uint4 *dst_lo = (uint4 *)(tile + (size_t)i * Wp + 8 * c);
         uint4 *dst_hi = (uint4 *)(tile + (size_t)i * Wp + half_row + 8 * c);
-        if (ALIGNED) {   // W is a multiple of 16 (so at least 16) and rows are 16-byte aligned
-            // Pairs of neighbouring pixels as two 16-bit fields of a word, P[j] = (pixel j - 2, pixel j - 1)
-            // counted from the chunk's first pixel: one byte permute each.  A sum of the five taps is at most
-            // 255 * 16, so plain 32-bit arithmetic on such words never carries from one field into the other
-            // and two output pixels cost four instructions.
-            const uint4 m = *(const uint4 *)(row + x0);
-            // left word: bytes 2, 3 = pixels x0 - 2, x0 - 1 (reflected at the row's start: pixels 2, 1)
-            const uint32_t l = x0 > 0 ? *(const uint32_t *)(row + x0 - 4) : __builtin_amdgcn_perm(0u, m.x, 0x01020c0cu);
-            // right word: bytes 0, 1 = pixels x0 + 16, x0 + 17 (reflected at the row's end: pixels 14, 13)
-            const uint32_t r = x0 + 16 < W ? *(const uint32_t *)(row + x0 + 16) : __builtin_amdgcn_perm(0u, m.w, 0x0c0c0102u);
-            const uint32_t wd[6] = {l, m.x, m.y, m.z, m.w, r};
-            uint32_t P[19];
-#pragma unroll
-            for (int j = 0; j < 19; j++) {
-                // first pixel of the pair is byte (j + 2) & 3 of word (j + 2) >> 2
-                const int w0 = (j + 2) >> 2, b0 = (j + 2) & 3;
-                P[j] = b0 == 0   ? __builtin_amdgcn_perm(0u, wd[w0], 0x0c010c00u)
-                       : b0 == 1 ? __builtin_amdgcn_perm(0u, wd[w0], 0x0c020c01u)
-                       : b0 == 2 ? __builtin_amdgcn_perm(0u, wd[w0], 0x0c030c02u)
-                                 : __builtin_amdgcn_perm(wd[w0 + 1], wd[w0], 0x0c040c03u);
-            }
-            uint32_t o[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++)
-                o[k] = sil_taps5(P[2 * k], P[2 * k + 1], P[2 * k + 2], P[2 * k + 3], P[2 * k + 4], 0u);
-            *dst_lo = make_uint4(o[0], o[1], o[2], o[3]);
-            *dst_hi = make_uint4(o[4], o[5], o[6], o[7]);
-        } else {
+        {
             uint32_t v[20];
 #pragma unroll
             for (int k = 0; k < 20; k++)
@@ -340,20 +394,26 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_blur_cv_kernel(SilArgs A)
     // at once) and a stretch of rows.  Lane j of a row takes the tile's j-th half chunk, so a wave's reads are
     // contiguous.
     const int octs = Wp >> 3;
+    const SilDiv dv_octs = sil_div_make(octs);
     int segs = FX_BLOCK / octs;
     segs = segs < 1 ? 1 : segs;
     const int rps = (nrows + segs - 1) / segs;
     uint8_t *out = A.blur + b * (int64_t)H * W;
     const bool row_qwords = (W & 7) == 0;
     for (int it = threadIdx.x; it < octs * segs; it += FX_BLOCK) {
-        const int j = it % octs, y0 = (it / octs) * rps;
+        const int sg = sil_div(it, dv_octs), j = it - sg * octs, y0 = sg * rps;
         const int y1 = y0 + rps < nrows ? y0 + rps : nrows;
         const int x = j < cpr ? 16 * j : 16 * (j - cpr) + 8;   // first column of the half chunk
         if (y0 >= y1 || x >= W)
             continue;
         const uint16_t *col = tile + 8 * j;
         auto ld = [&](int i) { return *(const uint4 *)(col + (size_t)i * Wp); };
-        uint4 c0 = ld(y0), c1 = ld(y0 + 1), c2 = ld(y0 + 2), c3 = ld(y0 + 3);
+        // Four output rows per round, the four rows they bring into the window read together and ahead of the
+        // arithmetic (the histogram's LDS atomics would otherwise keep every read behind them).
+        const int last = trows - 1;
+        auto ldc = [&](int i) { return ld(i < last ? i : last); };   // (a row past the tile is read for a step that does not run)
+        uint4 c[8];
+        c[0] = ld(y0), c[1] = ld(y0 + 1), c[2] = ld(y0 + 2), c[3] = ld(y0 + 3);
         uint32_t prev_lo = 0, prev_hi = 0, rep = 0;
         const int live = W - x;  // columns of this half chunk inside the image
         auto flush = [&]() {
@@ -373,32 +433,36 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_blur_cv_kernel(SilArgs A)
         // the high bytes of the four 16-bit fields of (ta, tb): one byte permute
         auto pack = [](uint32_t ta, uint32_t tb) { return __builtin_amdgcn_perm(tb, ta, 0x07050301u); };
         uint8_t *po = out + (int64_t)(r0 + y0) * W + x;
-        // (unrolled by five, the five rows of the window rotate through the registers without moves)
-        const uint16_t *nxt = col + (size_t)(y0 + 4) * Wp;   // the row entering the window
-#pragma unroll 5
-        for (int y = y0; y < y1; y++, po += W, nxt += Wp) {
-            const uint4 c4 = *(const uint4 *)nxt;
-            const uint32_t ta = sil_taps5(c0.x, c1.x, c2.x, c3.x, c4.x, 0x00800080u);
-            const uint32_t tb = sil_taps5(c0.y, c1.y, c2.y, c3.y, c4.y, 0x00800080u);
-            const uint32_t tc = sil_taps5(c0.z, c1.z, c2.z, c3.z, c4.z, 0x00800080u);
-            const uint32_t td = sil_taps5(c0.w, c1.w, c2.w, c3.w, c4.w, 0x00800080u);
-            const uint32_t o_lo = pack(ta, tb), o_hi = pack(tc, td);
-            if (row_qwords) {
-                *(uint2 *)po = make_uint2(o_lo, o_hi);
-            } else {
-                for (int k = 0; k < 8 && k < live; k++)
-                    po[k] = (uint8_t)((k < 4 ? o_lo : o_hi) >> (8 * (k & 3)));
+        for (int y = y0; y < y1; y += 4) {
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                c[4 + q] = ldc(y + 4 + q);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (y + q < y1) {
+                    const uint32_t ta = sil_taps5(c[q].x, c[q + 1].x, c[q + 2].x, c[q + 3].x, c[q + 4].x, 0x00800080u);
+                    const uint32_t tb = sil_taps5(c[q].y, c[q + 1].y, c[q + 2].y, c[q + 3].y, c[q + 4].y, 0x00800080u);
+                    const uint32_t tc = sil_taps5(c[q].z, c[q + 1].z, c[q + 2].z, c[q + 3].z, c[q + 4].z, 0x00800080u);
+                    const uint32_t td = sil_taps5(c[q].w, c[q + 1].w, c[q + 2].w, c[q + 3].w, c[q + 4].w, 0x00800080u);
+                    const uint32_t o_lo = pack(ta, tb), o_hi = pack(tc, td);
+                    if (row_qwords) {
+                        *(uint2 *)po = make_uint2(o_lo, o_hi);
+                    } else {
+                        for (int k = 0; k < 8 && k < live; k++)
+                            po[k] = (uint8_t)((k < 4 ? o_lo : o_hi) >> (8 * (k & 3)));
+                    }
+                    if (o_lo != prev_lo || o_hi != prev_hi) {
+                        flush();
+                        prev_lo = o_lo;
+                        prev_hi = o_hi;
+                    }
+                    rep++;
+                    po += W;
+                }
             }
-            if (o_lo != prev_lo || o_hi != prev_hi) {
-                flush();
-                prev_lo = o_lo;
-                prev_hi = o_hi;
-            }
-            rep++;
-            c0 = c1;
-            c1 = c2;
-            c2 = c3;
-            c3 = c4;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                c[q] = c[4 + q];
         }
         flush();
     }
@@ -453,21 +517,6 @@ __global__ __launch_bounds__(FX_WAVE) void sil_otsu_cv_kernel(const uint32_t *hi
 }
 
 // ------------------------------------------------------------ mask kernel
-// Division of small non-negative numbers (below 2^23) by a block-uniform divisor of at most 512 that is not
-// known at compile time: a multiplication by ceil(2^32 / d) instead of the twenty-odd instructions of a
-// 32-bit division, which the word loops below would otherwise pay once per mask word and pass.
-struct SilDiv {
-    uint32_t d, magic;
-};
-__device__ __forceinline__ SilDiv sil_div_make(int d)
-{
-    SilDiv v;
-    v.d = (uint32_t)d;
-    v.magic = d > 1 ? 0xFFFFFFFFu / (uint32_t)d + 1u : 0u;
-    return v;
-}
-__device__ __forceinline__ int sil_div(int n, SilDiv v) { return v.d > 1 ? (int)__umulhi((uint32_t)n, v.magic) : n; }
-
 // Word loops of a rows x cols bit mask: words per row, and for the morphology passes the split into
 // strips of `rs` rows of one word column per thread.
 struct SilGeom {
