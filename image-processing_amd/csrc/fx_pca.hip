@@ -595,16 +595,6 @@ __device__ __forceinline__ void pca_sets_reg_body(const PcaArgs &A, const int64_
     }
 }
 
-template <int PPL, bool RAGGED, int NW>
-// (32 points per lane, sets of 1025..2048 points: 96 registers of coordinates, two waves per SIMD)
-__global__ __launch_bounds__(FX_WAVE *NW, PPL > 16 ? 2 : FX_PCA_WAVES) void pca_sets_reg_kernel(PcaArgs A)
-{
-    const int64_t n_sets = A.n_sets_dev ? (int64_t)*A.n_sets_dev : A.n_sets;
-    if ((int64_t)blockIdx.x * NW >= n_sets)
-        return;  // a surplus block of a launch sized by an upper bound (the whole block leaves, before any barrier)
-    pca_sets_reg_body<PPL, RAGGED, NW>(A, blockIdx.x, n_sets);
-}
-
 // The sets pca_sets_full_kernel hands back (A.set_ids, their number in *A.n_sets_dev): a small grid walks the list.
 template <int PPL, int NW, bool RAGGED = false>
 __global__ __launch_bounds__(FX_WAVE *NW, FX_PCA_WAVES) void pca_sets_redo_kernel(PcaArgs A)
@@ -619,7 +609,7 @@ __global__ __launch_bounds__(FX_WAVE *NW, FX_PCA_WAVES) void pca_sets_redo_kerne
 // ------------------------------------------------- full sets: the C4 kernel
 // Equal-sized, 16-byte aligned 3-D sets of exactly 64 * PPL points (the
 // pipeline's 1024-point clouds): no per-point predicates, 1 / n and
-// 1 / (n - 1) from the host.  Same float64 arithmetic as pca_sets_reg_kernel.
+// 1 / (n - 1) from the host.  Same float64 arithmetic as pca_sets_reg_body.
 // What differs is how the few points are handled that float32 cannot settle
 // (the candidates for the exact maximum, points within rounding of a bin
 // edge): instead of a float64 branch per point index (thirty-two inlined
@@ -1690,8 +1680,7 @@ int launch_quad_sets(const PcaArgs &A, hipStream_t s)
 
 int launch_reg_sets(const PcaArgs &A, int64_t max_points, bool ragged, hipStream_t s)
 {
-    constexpr int NW = FX_PCA_NW;  // sets (waves) per block
-    if (max_points <= QUAD_MAX_POINTS && A.redo_list)
+    if (max_points <= QUAD_MAX_POINTS)
         return launch_quad_sets(A, s);
     if (!ragged && !A.offsets && !A.set_ids) {
         if (max_points == 1024)
@@ -1699,42 +1688,14 @@ int launch_reg_sets(const PcaArgs &A, int64_t max_points, bool ragged, hipStream
         if (max_points == 512)
             return launch_full_sets<8>(A, s);
     }
-    if (A.redo_list)   // (without a redo list: the kernels that handle every set themselves)
-        return max_points <= 512 ? launch_ragged_sets<8>(A, s) : launch_ragged_sets<16>(A, s);
-    const int64_t blocks = (A.n_sets + NW - 1) / NW;
-    FX_REQUIRE(blocks <= 0x7fffffffLL, "fx_pca_batch_f32: too many sets for one launch");
-    const dim3 grid((unsigned)blocks), block(FX_WAVE * NW);
-    if (ragged) {
-        if (max_points <= 256)
-            hipLaunchKernelGGL((pca_sets_reg_kernel<4, true, NW>), grid, block, 0, s, A);
-        else if (max_points <= 512)
-            hipLaunchKernelGGL((pca_sets_reg_kernel<8, true, NW>), grid, block, 0, s, A);
-        else
-            hipLaunchKernelGGL((pca_sets_reg_kernel<16, true, NW>), grid, block, 0, s, A);
-    } else {
-        if (max_points <= 256)
-            hipLaunchKernelGGL((pca_sets_reg_kernel<4, false, NW>), grid, block, 0, s, A);
-        else if (max_points <= 512)
-            hipLaunchKernelGGL((pca_sets_reg_kernel<8, false, NW>), grid, block, 0, s, A);
-        else
-            hipLaunchKernelGGL((pca_sets_reg_kernel<16, false, NW>), grid, block, 0, s, A);
-    }
-    FX_HIP_CHECK(hipGetLastError());
-    return FX_OK;
+    return max_points <= 512 ? launch_ragged_sets<8>(A, s) : launch_ragged_sets<16>(A, s);
 }
 
 int launch_small_sets(const PcaArgs &A, int64_t max_points, hipStream_t s)
 {
     if (max_points > REG_SET_MAX_POINTS && max_points <= 2 * REG_SET_MAX_POINTS) {
-        // sets of 1025..2048 points: the register kernels with 32 points per lane
-        if (A.redo_list)
-            return launch_ragged_sets<32>(A, s);
-        constexpr int NW = FX_PCA_NW;
-        const int64_t blocks = (A.n_sets + NW - 1) / NW;
-        FX_REQUIRE(blocks <= 0x7fffffffLL, "fx_pca_batch_f32: too many sets for one launch");
-        hipLaunchKernelGGL((pca_sets_reg_kernel<32, true, NW>), dim3((unsigned)blocks), dim3(FX_WAVE * NW), 0, s, A);
-        FX_HIP_CHECK(hipGetLastError());
-        return FX_OK;
+        // sets of 1025..2048 points: the register kernel with 32 points per lane
+        return launch_ragged_sets<32>(A, s);
     }
     // keep each block's LDS near 48 KiB so that three blocks share a CU
     if (max_points <= 1024)
@@ -2157,7 +2118,7 @@ extern "C" int fx_pca_batch_f32(const float *d_pts, const int64_t *d_offsets, in
     }
     int32_t *d_ids = nullptr;
     if (n_small > 0) {
-        d_ids = (int32_t *)guard.scratch((size_t)n_small * sizeof(int32_t), 0);
+        d_ids = (int32_t *)guard.scratch(((size_t)n_small + (size_t)B + 64) * sizeof(int32_t), 0);
         if (!d_ids) {
             free(h_ids);
             free(h_large_sizes);
@@ -2180,12 +2141,16 @@ extern "C" int fx_pca_batch_f32(const float *d_pts, const int64_t *d_offsets, in
         PcaArgs S = A;
         S.set_ids = d_ids;
         S.n_sets = n_reg;
+        S.redo_count = d_ids + n_small;   // (the two launches run one after the other: they share the list)
+        S.redo_list = d_ids + n_small + 64;
         rc = launch_reg_sets(S, max_reg, true, s);
     }
     if (rc == FX_OK && n_small > n_reg) {
         PcaArgs S = A;
         S.set_ids = d_ids + n_reg;
         S.n_sets = n_small - n_reg;
+        S.redo_count = d_ids + n_small;
+        S.redo_list = d_ids + n_small + 64;
         rc = launch_small_sets(S, max_small, s);
     }
     if (rc == FX_OK && n_large > 0)
