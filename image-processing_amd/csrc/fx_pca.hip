@@ -1268,7 +1268,7 @@ __global__ __launch_bounds__(FX_WAVE *NW, 3) void pca_sets_quad_kernel(PcaArgs A
 constexpr int CLOUD_CHUNK = 16384;
 constexpr int CLOUD_THREADS = 256;
 constexpr int CLOUD_WAVES = CLOUD_THREADS / FX_WAVE;
-// per-chunk record, doubles: 0-2 coordinate sums, 3 max r^2, 4-9 centred second moments, 10 max |projection|
+// per-chunk record, doubles: 0-2 sums of p - pivot, 3 max r^2, 4-9 sums of (p - pivot)(p - pivot)^T, 10 max |projection|
 constexpr int PART = 12;
 // per-cloud record, doubles: 0-2 mean, 3 rmax (0 = no scaling), 4-6 first principal axis
 constexpr int STATE = 8;
@@ -1346,6 +1346,8 @@ struct CloudPoint {
 };
 __device__ __forceinline__ CloudPoint cloud_point(const float *g, int64_t i, int dims)
 {
+    // (three 4-byte loads per point: a wave's 64 lanes then cover 768 contiguous bytes three times; one 12-byte
+    // load per lane was 20 % slower over the whole chain)
     CloudPoint p;
     p.x = (double)g[i * dims];
     p.y = (double)g[i * dims + 1];
@@ -1353,82 +1355,75 @@ __device__ __forceinline__ CloudPoint cloud_point(const float *g, int64_t i, int
     return p;
 }
 
+// First pass: sums of d = p - pivot and of d d^T over the chunk, the pivot being the cloud's first point (as in
+// the set kernels: mean = pivot + sum d / n, centred second moments = sum d d^T - (sum d)(sum d)^T / n, so the
+// mean does not have to be known before the second moments are summed and one pass over the cloud is saved).
 __device__ __forceinline__ void cloud_sum_body(const PcaArgs &A, const CloudWork &Wk, const int chunk, double *red)
 {
     const ChunkView v = chunk_view(A, Wk, chunk);
-    double sx = 0.0, sy = 0.0, sz = 0.0;
+    const CloudPoint k = cloud_point(v.g, 0, A.dims);
+    double a9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int64_t i = v.i0 + threadIdx.x; i < v.i1; i += CLOUD_THREADS) {
         const CloudPoint p = cloud_point(v.g, i, A.dims);
-        sx += p.x;
-        sy += p.y;
-        sz += p.z;
+        const double dx = p.x - k.x, dy = p.y - k.y, dz = p.z - k.z;
+        a9[0] += dx;
+        a9[1] += dy;
+        a9[2] += dz;
+        a9[3] = fma(dx, dx, a9[3]);
+        a9[4] = fma(dx, dy, a9[4]);
+        a9[5] = fma(dx, dz, a9[5]);
+        a9[6] = fma(dy, dy, a9[6]);
+        a9[7] = fma(dy, dz, a9[7]);
+        a9[8] = fma(dz, dz, a9[8]);
     }
-    sx = cloud_block_reduce<false>(sx, red);
-    sy = cloud_block_reduce<false>(sy, red);
-    sz = cloud_block_reduce<false>(sz, red);
-    if (threadIdx.x == 0) {
-        double *out = Wk.part + (int64_t)chunk * PART;
-        out[0] = sx;
-        out[1] = sy;
-        out[2] = sz;
+    double *out = Wk.part + (int64_t)chunk * PART;
+#pragma unroll
+    for (int q = 0; q < 9; q++) {
+        const double tot = cloud_block_reduce<false>(a9[q], red);
+        if (threadIdx.x == 0)
+            out[q < 3 ? q : q + 1] = tot;   // fields 0-2 and 4-9; field 3 is the largest r^2
     }
 }
 
-// STAGE 0: max r^2 of the centred points (normalize only); STAGE 1: centred second moments.
-template <int STAGE>
-__device__ __forceinline__ void cloud_moment_body(const PcaArgs &A, const CloudWork &Wk, const int chunk, double *red)
+// What every block of a cloud derives from the combined chunk records: mean, covariance sums about the mean.
+struct CloudMoments {
+    double mx, my, mz;
+    double S[6];
+};
+__device__ __forceinline__ CloudMoments cloud_moments(const PcaArgs &A, const CloudWork &Wk, const ChunkView &v, double *red)
+{
+    const CloudPoint k = cloud_point(v.g, 0, A.dims);
+    const double dn = (double)v.n;
+    double t[9];
+#pragma unroll
+    for (int q = 0; q < 9; q++)
+        t[q] = cloud_combine<false>(Wk.part, v.first, v.nch, q < 3 ? q : q + 1, red);
+    const double ox = t[0] / dn, oy = t[1] / dn, oz = t[2] / dn;   // mean - pivot
+    CloudMoments m;
+    m.mx = k.x + ox, m.my = k.y + oy, m.mz = k.z + oz;
+    m.S[0] = fma(-t[0], ox, t[3]);
+    m.S[1] = fma(-t[0], oy, t[4]);
+    m.S[2] = fma(-t[0], oz, t[5]);
+    m.S[3] = fma(-t[1], oy, t[6]);
+    m.S[4] = fma(-t[1], oz, t[7]);
+    m.S[5] = fma(-t[2], oz, t[8]);
+    return m;
+}
+
+// normalize only: the largest r^2 of the centred points of the chunk
+__device__ __forceinline__ void cloud_rmax_body(const PcaArgs &A, const CloudWork &Wk, const int chunk, double *red)
 {
     const ChunkView v = chunk_view(A, Wk, chunk);
-    const double dn = (double)v.n;
-    const double mx = cloud_combine<false>(Wk.part, v.first, v.nch, 0, red) / dn;
-    const double my = cloud_combine<false>(Wk.part, v.first, v.nch, 1, red) / dn;
-    const double mz = cloud_combine<false>(Wk.part, v.first, v.nch, 2, red) / dn;
-    double *out = Wk.part + (int64_t)chunk * PART;
-    if (STAGE == 0) {
-        double r2 = 0.0;
-        for (int64_t i = v.i0 + threadIdx.x; i < v.i1; i += CLOUD_THREADS) {
-            const CloudPoint p = cloud_point(v.g, i, A.dims);
-            const double dx = p.x - mx, dy = p.y - my, dz = p.z - mz;
-            r2 = fmax(r2, dx * dx + dy * dy + dz * dz);
-        }
-        r2 = cloud_block_reduce<true>(r2, red);
-        if (threadIdx.x == 0)
-            out[3] = r2;
-        return;
-    }
-    double rmax = 0.0;
-    if (A.normalize)
-        rmax = sqrt(cloud_combine<true>(Wk.part, v.first, v.nch, 3, red));
-    const bool scale = A.normalize && rmax > 0.0;
-    double S[6] = {0, 0, 0, 0, 0, 0};
+    const CloudMoments m = cloud_moments(A, Wk, v, red);
+    double r2 = 0.0;
     for (int64_t i = v.i0 + threadIdx.x; i < v.i1; i += CLOUD_THREADS) {
         const CloudPoint p = cloud_point(v.g, i, A.dims);
-        double dx = p.x - mx, dy = p.y - my, dz = p.z - mz;
-        if (scale) {
-            dx /= rmax;
-            dy /= rmax;
-            dz /= rmax;
-        }
-        S[0] = fma(dx, dx, S[0]);
-        S[1] = fma(dx, dy, S[1]);
-        S[2] = fma(dx, dz, S[2]);
-        S[3] = fma(dy, dy, S[3]);
-        S[4] = fma(dy, dz, S[4]);
-        S[5] = fma(dz, dz, S[5]);
+        const double dx = p.x - m.mx, dy = p.y - m.my, dz = p.z - m.mz;
+        r2 = fmax(r2, dx * dx + dy * dy + dz * dz);
     }
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-        const double tot = cloud_block_reduce<false>(S[k], red);
-        if (threadIdx.x == 0)
-            out[4 + k] = tot;
-    }
-    if (threadIdx.x == 0 && chunk == v.first) {
-        double *st = Wk.state + (int64_t)v.cloud * STATE;
-        st[0] = mx;
-        st[1] = my;
-        st[2] = mz;
-        st[3] = scale ? rmax : 0.0;
-    }
+    r2 = cloud_block_reduce<true>(r2, red);
+    if (threadIdx.x == 0)
+        Wk.part[(int64_t)chunk * PART + 3] = r2;
 }
 
 __device__ __forceinline__ double cloud_projection(const CloudPoint &p, const double *st)
@@ -1448,18 +1443,22 @@ __device__ __forceinline__ double cloud_projection(const CloudPoint &p, const do
 __device__ __forceinline__ void cloud_proj_body(const PcaArgs &A, const CloudWork &Wk, const int chunk, double *red)
 {
     const ChunkView v = chunk_view(A, Wk, chunk);
+    const CloudMoments m = cloud_moments(A, Wk, v, red);
+    double rmax = 0.0;
+    if (A.normalize)
+        rmax = sqrt(cloud_combine<true>(Wk.part, v.first, v.nch, 3, red));
+    const bool scale = A.normalize && rmax > 0.0;
     double S[6];
 #pragma unroll
     for (int k = 0; k < 6; k++)
-        S[k] = cloud_combine<false>(Wk.part, v.first, v.nch, 4 + k, red);
+        S[k] = scale ? m.S[k] / (rmax * rmax) : m.S[k];   // moments of the points divided by rmax
     double head[9], lam[3], v1[3];
     cov_to_head(S, v.n, head, lam, v1);
     double st[STATE];
-    const double *gs = Wk.state + (int64_t)v.cloud * STATE;
-    st[0] = gs[0];
-    st[1] = gs[1];
-    st[2] = gs[2];
-    st[3] = gs[3];
+    st[0] = m.mx;
+    st[1] = m.my;
+    st[2] = m.mz;
+    st[3] = scale ? rmax : 0.0;
     st[4] = v1[0];
     st[5] = v1[1];
     st[6] = v1[2];
@@ -1485,9 +1484,9 @@ __device__ __forceinline__ void cloud_proj_body(const PcaArgs &A, const CloudWor
     // the cloud computed the same values, the first one stores them
     if (threadIdx.x == 0 && chunk == v.first) {
         double *wst = Wk.state + (int64_t)v.cloud * STATE;
-        wst[4] = v1[0];
-        wst[5] = v1[1];
-        wst[6] = v1[2];
+#pragma unroll
+        for (int k = 0; k < 7; k++)
+            wst[k] = st[k];
     }
 }
 
@@ -1562,13 +1561,12 @@ __global__ __launch_bounds__(CLOUD_THREADS) void cloud_sum_kernel(PcaArgs A, Clo
         cloud_sum_body(A, Wk, chunk, red);
 }
 
-template <int STAGE>
-__global__ __launch_bounds__(CLOUD_THREADS) void cloud_moment_kernel(PcaArgs A, CloudWork Wk)
+__global__ __launch_bounds__(CLOUD_THREADS) void cloud_rmax_kernel(PcaArgs A, CloudWork Wk)
 {
     __shared__ double red[CLOUD_WAVES];
     const int n = cloud_list_length(Wk.n_chunks_dev);
     for (int chunk = blockIdx.x; chunk < n; chunk += gridDim.x)
-        cloud_moment_body<STAGE>(A, Wk, chunk, red);
+        cloud_rmax_body(A, Wk, chunk, red);
 }
 
 __global__ __launch_bounds__(CLOUD_THREADS) void cloud_proj_kernel(PcaArgs A, CloudWork Wk)
@@ -1876,8 +1874,7 @@ int launch_large_clouds(const PcaArgs &A, const int32_t *h_sets, const int64_t *
     const dim3 grid((unsigned)n_chunks), block(CLOUD_THREADS);
     hipLaunchKernelGGL(cloud_sum_kernel, grid, block, 0, s, A, Wk);
     if (A.normalize)
-        hipLaunchKernelGGL(cloud_moment_kernel<0>, grid, block, 0, s, A, Wk);
-    hipLaunchKernelGGL(cloud_moment_kernel<1>, grid, block, 0, s, A, Wk);
+        hipLaunchKernelGGL(cloud_rmax_kernel, grid, block, 0, s, A, Wk);
     hipLaunchKernelGGL(cloud_proj_kernel, grid, block, 0, s, A, Wk);
     hipLaunchKernelGGL(cloud_hist_kernel, grid, block, 0, s, A, Wk);
     hipLaunchKernelGGL(cloud_finish_kernel, dim3((unsigned)n_clouds), dim3(FX_BLOCK), 0, s, A, Wk);
@@ -1974,8 +1971,7 @@ int launch_ragged_on_device(const PcaArgs &A, int64_t B, int64_t total, FxCallGu
     const dim3 grid((unsigned)(max_chunks < 2048 ? max_chunks : 2048)), block(CLOUD_THREADS);
     hipLaunchKernelGGL(cloud_sum_kernel, grid, block, 0, s, A, Wk);
     if (A.normalize)
-        hipLaunchKernelGGL(cloud_moment_kernel<0>, grid, block, 0, s, A, Wk);
-    hipLaunchKernelGGL(cloud_moment_kernel<1>, grid, block, 0, s, A, Wk);
+        hipLaunchKernelGGL(cloud_rmax_kernel, grid, block, 0, s, A, Wk);
     hipLaunchKernelGGL(cloud_proj_kernel, grid, block, 0, s, A, Wk);
     hipLaunchKernelGGL(cloud_hist_kernel, grid, block, 0, s, A, Wk);
     hipLaunchKernelGGL(cloud_finish_kernel, dim3((unsigned)(max_clouds < 1024 ? max_clouds : 1024)), dim3(FX_BLOCK), 0, s, A,
