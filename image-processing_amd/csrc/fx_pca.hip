@@ -1355,6 +1355,49 @@ __device__ __forceinline__ CloudPoint cloud_point(const float *g, int64_t i, int
     return p;
 }
 
+// Calls f(x, y, z) for every point of the chunk.  Where the chunk's floats are 16-byte aligned a thread takes
+// four consecutive points with three (2-D: two) 16-byte loads -- a wave then reads 3 KB of contiguous memory per
+// round, as the set kernels do -- and only the up to three points before the first aligned one and after the
+// last whole group are read one by one.
+template <typename F>
+__device__ __forceinline__ void cloud_for_points(const PcaArgs &A, const ChunkView &v, F f)
+{
+    const int dims = A.dims;
+    int64_t ib = v.i0;
+    for (int k = 0; k < 4 && ib < v.i1 && ((uintptr_t)(v.g + ib * dims) & 15u); k++)
+        ib++;
+    if ((uintptr_t)(v.g + ib * dims) & 15u)
+        ib = v.i1;   // (2-D points at an odd float offset never reach alignment: all one by one)
+    const int64_t ng = (v.i1 - ib) / 4, ie = ib + 4 * ng;
+    for (int64_t i = v.i0 + threadIdx.x; i < ib; i += CLOUD_THREADS) {
+        const CloudPoint p = cloud_point(v.g, i, dims);
+        f(p.x, p.y, p.z);
+    }
+    if (dims == 3) {
+        const float4 *g4 = reinterpret_cast<const float4 *>(v.g + ib * 3);
+        for (int64_t g = threadIdx.x; g < ng; g += CLOUD_THREADS) {
+            const float4 a = g4[3 * g], b = g4[3 * g + 1], c = g4[3 * g + 2];
+            f((double)a.x, (double)a.y, (double)a.z);
+            f((double)a.w, (double)b.x, (double)b.y);
+            f((double)b.z, (double)b.w, (double)c.x);
+            f((double)c.y, (double)c.z, (double)c.w);
+        }
+    } else {
+        const float4 *g4 = reinterpret_cast<const float4 *>(v.g + ib * 2);
+        for (int64_t g = threadIdx.x; g < ng; g += CLOUD_THREADS) {
+            const float4 a = g4[2 * g], b = g4[2 * g + 1];
+            f((double)a.x, (double)a.y, 0.0);
+            f((double)a.z, (double)a.w, 0.0);
+            f((double)b.x, (double)b.y, 0.0);
+            f((double)b.z, (double)b.w, 0.0);
+        }
+    }
+    for (int64_t i = ie + threadIdx.x; i < v.i1; i += CLOUD_THREADS) {
+        const CloudPoint p = cloud_point(v.g, i, dims);
+        f(p.x, p.y, p.z);
+    }
+}
+
 // First pass: sums of d = p - pivot and of d d^T over the chunk, the pivot being the cloud's first point (as in
 // the set kernels: mean = pivot + sum d / n, centred second moments = sum d d^T - (sum d)(sum d)^T / n, so the
 // mean does not have to be known before the second moments are summed and one pass over the cloud is saved).
@@ -1363,9 +1406,8 @@ __device__ __forceinline__ void cloud_sum_body(const PcaArgs &A, const CloudWork
     const ChunkView v = chunk_view(A, Wk, chunk);
     const CloudPoint k = cloud_point(v.g, 0, A.dims);
     double a9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int64_t i = v.i0 + threadIdx.x; i < v.i1; i += CLOUD_THREADS) {
-        const CloudPoint p = cloud_point(v.g, i, A.dims);
-        const double dx = p.x - k.x, dy = p.y - k.y, dz = p.z - k.z;
+    cloud_for_points(A, v, [&](double px, double py, double pz) {
+        const double dx = px - k.x, dy = py - k.y, dz = pz - k.z;
         a9[0] += dx;
         a9[1] += dy;
         a9[2] += dz;
@@ -1375,7 +1417,7 @@ __device__ __forceinline__ void cloud_sum_body(const PcaArgs &A, const CloudWork
         a9[6] = fma(dy, dy, a9[6]);
         a9[7] = fma(dy, dz, a9[7]);
         a9[8] = fma(dz, dz, a9[8]);
-    }
+    });
     double *out = Wk.part + (int64_t)chunk * PART;
 #pragma unroll
     for (int q = 0; q < 9; q++) {
@@ -1416,11 +1458,10 @@ __device__ __forceinline__ void cloud_rmax_body(const PcaArgs &A, const CloudWor
     const ChunkView v = chunk_view(A, Wk, chunk);
     const CloudMoments m = cloud_moments(A, Wk, v, red);
     double r2 = 0.0;
-    for (int64_t i = v.i0 + threadIdx.x; i < v.i1; i += CLOUD_THREADS) {
-        const CloudPoint p = cloud_point(v.g, i, A.dims);
-        const double dx = p.x - m.mx, dy = p.y - m.my, dz = p.z - m.mz;
+    cloud_for_points(A, v, [&](double px, double py, double pz) {
+        const double dx = px - m.mx, dy = py - m.my, dz = pz - m.mz;
         r2 = fmax(r2, dx * dx + dy * dy + dz * dz);
-    }
+    });
     r2 = cloud_block_reduce<true>(r2, red);
     if (threadIdx.x == 0)
         Wk.part[(int64_t)chunk * PART + 3] = r2;
@@ -1463,8 +1504,11 @@ __device__ __forceinline__ void cloud_proj_body(const PcaArgs &A, const CloudWor
     st[5] = v1[1];
     st[6] = v1[2];
     double top = 0.0;
-    for (int64_t i = v.i0 + threadIdx.x; i < v.i1; i += CLOUD_THREADS)
-        top = fmax(top, cloud_projection(cloud_point(v.g, i, A.dims), st));
+    cloud_for_points(A, v, [&](double px, double py, double pz) {
+        CloudPoint p;
+        p.x = px, p.y = py, p.z = pz;
+        top = fmax(top, cloud_projection(p, st));
+    });
     top = cloud_block_reduce<true>(top, red);
     if (threadIdx.x == 0) {
         Wk.part[(int64_t)chunk * PART + 10] = top;
@@ -1505,8 +1549,11 @@ __device__ __forceinline__ void cloud_hist_body(const PcaArgs &A, const CloudWor
     if (top > 0.0) {
         const double step = top / (double)nb;
         const double inv_step = (double)nb / top;
-        for (int64_t i = v.i0 + threadIdx.x; i < v.i1; i += CLOUD_THREADS)
-            atomicAdd(&hist[fx_hist_bin(cloud_projection(cloud_point(v.g, i, A.dims), st), step, inv_step, nb)], 1u);
+        cloud_for_points(A, v, [&](double px, double py, double pz) {
+            CloudPoint p;
+            p.x = px, p.y = py, p.z = pz;
+            atomicAdd(&hist[fx_hist_bin(cloud_projection(p, st), step, inv_step, nb)], 1u);
+        });
     }
     __syncthreads();
     if (threadIdx.x < HIST_MAX)
