@@ -755,13 +755,30 @@ __device__ SilRuns sil_label(const uint32_t *m, int rows, int wc, SilDiv dv, int
     const int nw = rows * wc;
     const int per = (nw + FX_BLOCK - 1) / FX_BLOCK;
     __syncthreads();
+    // (a thread's run counts are kept for the second loop when they are few: 224 x 224 views have seven words
+    // per thread)
+    constexpr int KEEP = 8;
+    uint32_t kept[KEEP];
     {
         uint32_t local = 0;
-        for (int j = 0; j < per; j++) {
-            const int wi = t * per + j;
-            if (wi < nw) {
-                const int y = sil_div(wi, dv), w = wi - y * wc;
-                local += __popc(sil_starts(m + y * wpr, w));
+        if (per <= KEEP) {
+#pragma unroll
+            for (int j = 0; j < KEEP; j++) {
+                const int wi = t * per + j;
+                kept[j] = 0;
+                if (j < per && wi < nw) {
+                    const int y = sil_div(wi, dv), w = wi - y * wc;
+                    kept[j] = __popc(sil_starts(m + y * wpr, w));
+                }
+                local += kept[j];
+            }
+        } else {
+            for (int j = 0; j < per; j++) {
+                const int wi = t * per + j;
+                if (wi < nw) {
+                    const int y = sil_div(wi, dv), w = wi - y * wc;
+                    local += __popc(sil_starts(m + y * wpr, w));
+                }
             }
         }
         // exclusive prefix over the block: wave scan, then the waves in front
@@ -784,12 +801,23 @@ __device__ SilRuns sil_label(const uint32_t *m, int rows, int wc, SilDiv dv, int
             base += w < fx_wave() ? s_scan[w] : 0u;
             total += s_scan[w];
         }
-        for (int j = 0; j < per; j++) {
-            const int wi = t * per + j;
-            if (wi < nw) {
-                const int y = sil_div(wi, dv), w = wi - y * wc;
-                pre[wi] = base;
-                base += __popc(sil_starts(m + y * wpr, w));
+        if (per <= KEEP) {
+#pragma unroll
+            for (int j = 0; j < KEEP; j++) {
+                const int wi = t * per + j;
+                if (j < per && wi < nw) {
+                    pre[wi] = base;
+                    base += kept[j];
+                }
+            }
+        } else {
+            for (int j = 0; j < per; j++) {
+                const int wi = t * per + j;
+                if (wi < nw) {
+                    const int y = sil_div(wi, dv), w = wi - y * wc;
+                    pre[wi] = base;
+                    base += __popc(sil_starts(m + y * wpr, w));
+                }
             }
         }
         if (t == 0)
@@ -987,7 +1015,7 @@ __global__ __launch_bounds__(FX_BLOCK, 5) void sil_mask_kernel(SilArgs A)
     __shared__ unsigned long long s_tick[24];
 #endif
 
-    const int t = threadIdx.x;
+    const int t_block = threadIdx.x;
     const int nw = A.rows * A.wpr;
     uint32_t *mA = (uint32_t *)sil_smem;
     uint32_t *mB = mA + nw;
@@ -999,6 +1027,13 @@ __global__ __launch_bounds__(FX_BLOCK, 5) void sil_mask_kernel(SilArgs A)
     const SilDiv dvV = sil_div_make((W + 32) >> 5), dvP = sil_div_make(res >> 4);
 
     for (int64_t b = blockIdx.x; b < A.B; b += gridDim.x) {
+        // The thread index is made opaque once per view: what is derived from it (addresses into the LDS arrays and
+        // the scratch buffers) is then computed where it is used instead of being kept -- and, at 96 registers,
+        // spilled -- across the whole loop over the views.
+        int t = t_block;
+        asm volatile("" : "+v"(t));
+        unsigned long long zero64 = 0ull;   // (likewise: a 64-bit zero hoisted out of the loop ends up spilled)
+        asm volatile("" : "+v"(zero64));
         __syncthreads();
         // ---- Otsu level (reference :101-126): float64 in the reference's order
         if (!CV)
@@ -1006,11 +1041,11 @@ __global__ __launch_bounds__(FX_BLOCK, 5) void sil_mask_kernel(SilArgs A)
         if (t < SV_N)
             s_v[t] = t == SV_MINX ? W : t == SV_MINY ? H : (t == SV_MAXX || t == SV_MAXY) ? -1 : 0;
         if (t == 0) {
-            s_best = 0ull;
-            s_first = ~0ull;
+            s_best = zero64;
+            s_first = ~zero64;
         }
         if (t < 80)
-            s_mom[t >> 3][t & 7] = 0ull;
+            s_mom[t >> 3][t & 7] = zero64;
         __syncthreads();
         SIL_TICK(0);
         constexpr bool cv = CV;
@@ -1366,7 +1401,7 @@ __global__ __launch_bounds__(FX_BLOCK, 5) void sil_mask_kernel(SilArgs A)
             if (again) {   // block-uniform
                 __syncthreads();
                 if (t == 0)
-                    s_best = 0ull;
+                    s_best = zero64;
                 __syncthreads();
                 return true;
             }

@@ -31,13 +31,15 @@ for (B, H, W, res, kind) in ((20000, 224, 224, 224, "views"), (12000, 200, 152, 
                 p[(d2 <= r1 * r1) & (d2 >= r0 * r0)] = 30
         imgs = torch.from_numpy(pats).to(dev).repeat((B + 299) // 300, 1, 1)[:B].contiguous()
         imgs = (imgs.to(torch.int16) + torch.randint(-6, 7, imgs.shape, device=dev, dtype=torch.int16)).clamp_(0, 255).to(torch.uint8)
-    a = eng.silhouette_batch(imgs, res, 0.05, True)["mask"]
-    b = eng.silhouette_batch(imgs, res, 0.05, True)["mask"]
-    torch.cuda.synchronize()
-    same = bool(torch.equal(a, b))
-    idx = rng.choice(B, 24, replace=False)
-    bad = 0
-    for i in idx:
-        want = cpu_ref.silhouette_cv(imgs[int(i)].cpu().numpy(), res, 0.05, True)[0]
-        bad += int(not np.array_equal(a[int(i)].cpu().numpy(), want))
-    print(f"{kind} B={B} {H}x{W}->{res}: runs agree {same}, oracle mismatches {bad}/24", flush=True)
+    for backend in ("opencv", "pil"):
+        a = eng.silhouette_batch(imgs, res, 0.05, True, backend=backend)["mask"]
+        b = eng.silhouette_batch(imgs, res, 0.05, True, backend=backend)["mask"]
+        torch.cuda.synchronize()
+        same = bool(torch.equal(a, b))
+        idx = rng.choice(B, 24, replace=False)   # most of them from a block's later rounds
+        bad = 0
+        oracle = cpu_ref.silhouette_cv if backend == "opencv" else cpu_ref.silhouette
+        for i in idx:
+            want = oracle(imgs[int(i)].cpu().numpy(), res, 0.05, True)[0]
+            bad += int(not np.array_equal(a[int(i)].cpu().numpy(), want))
+        print(f"{kind} {backend} B={B} {H}x{W}->{res}: runs agree {same}, oracle mismatches {bad}/24", flush=True)
