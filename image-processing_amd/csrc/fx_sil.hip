@@ -257,7 +257,7 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_blur_kernel(SilArgs A)
 // ---------------------------------------------------------------------------
 constexpr int SIL_CV_HALO = 2;
 // mask words (32 blurred pixels each) a thread of the mask kernel requests together when it thresholds a view:
-// (seven would make a 224 x 224 view one wait for global memory instead of two, but spill: 1.43 -> 1.52 ms)
+// (seven would make a 224 x 224 view one wait for global memory instead of two; measured: no faster)
 constexpr int SIL_TH_UNR = 4;
 
 __device__ __forceinline__ int sil_refl101(int i, int n)
