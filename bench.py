@@ -423,7 +423,9 @@ def main(argv=None):
     out = None
     if rank == 0:
         kavg = sum(kernel_ms) / len(kernel_ms)
-        achieved = units * wl["bytes_per_unit"] / (kavg * 1e-3) / 1e9 if kavg > 0 else 0.0
+        # a call that ran its units as several launches of the kernel timed one of them
+        launch_units = (eng.profile_last_units() if kind == "sil+hu" else 0) or units
+        achieved = launch_units * wl["bytes_per_unit"] / (kavg * 1e-3) / 1e9 if kavg > 0 else 0.0
         traffic = None
         tfile = ROOT / "profiles" / "traffic.json"
         if tfile.exists():
@@ -449,7 +451,7 @@ def main(argv=None):
                          "kernel": {"pca": "pca_sets_full_kernel", "hu": "hu_band_kernel", "hu+cpca": "hu_band_kernel",
                                     "tail": "hu_band_kernel", "sil+hu": "sil_mask_kernel",
                                     "views+hu": "render_views_kernel"}[kind],
-                         "kernel_ms": kavg, "units_per_launch": units},
+                         "kernel_ms": kavg, "units_per_launch": launch_units},
         }
         if kind == "tail":
             out["config"]["cloud_points_total"] = wl["cloud_points_total"]

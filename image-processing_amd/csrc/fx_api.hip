@@ -23,7 +23,23 @@ struct StreamState {
     size_t pin_bytes = 0;
     hipEvent_t pin_ev = nullptr;  // recorded behind the copies out of `pin`
     bool pin_busy = false;
+    hipStream_t side = nullptr;   // second stream of calls that overlap two halves of their work
+    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
 };
+
+void release_side(StreamState &st)
+{
+    if (st.side) {
+        (void)hipStreamSynchronize(st.side);
+        (void)hipStreamDestroy(st.side);
+    }
+    st.side = nullptr;
+    if (st.fork_ev)
+        (void)hipEventDestroy(st.fork_ev);
+    if (st.join_ev)
+        (void)hipEventDestroy(st.join_ev);
+    st.fork_ev = st.join_ev = nullptr;
+}
 
 void release_pin(StreamState &st)
 {
@@ -43,8 +59,10 @@ std::mutex g_mu;
 std::map<std::pair<int, hipStream_t>, std::unique_ptr<StreamState>> g_streams;
 
 bool g_profile = false;
-thread_local hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
-thread_local bool g_ev_valid = false;
+// two event pairs: a call that runs two launches of its dominant kernel side by side brackets both
+thread_local hipEvent_t g_ev[2][2] = {};
+thread_local bool g_ev_valid[2] = {false, false};
+thread_local int64_t g_prof_units = 0;
 
 StreamState *stream_state(hipStream_t stream)
 {
@@ -148,18 +166,62 @@ int FxCallGuard::staged()
     return FX_OK;
 }
 
-FxProfileScope::FxProfileScope(hipStream_t s) : stream(s), active(g_profile)
+hipStream_t FxCallGuard::fork()
+{
+    if (!state) {
+        fx_set_error("fx fork: no current device");
+        return nullptr;
+    }
+    StreamState &st = *static_cast<StreamState *>(state);
+    hipError_t e = hipSuccess;
+    if (!st.side) {
+        hipStream_t side = nullptr;
+        // non-blocking: ordered against `stream` by the two events only, also when `stream` is the null stream
+        if ((e = hipStreamCreateWithFlags(&side, hipStreamNonBlocking)) == hipSuccess &&
+            (e = hipEventCreateWithFlags(&st.fork_ev, hipEventDisableTiming)) == hipSuccess &&
+            (e = hipEventCreateWithFlags(&st.join_ev, hipEventDisableTiming)) == hipSuccess) {
+            st.side = side;
+        } else {
+            if (side)
+                (void)hipStreamDestroy(side);
+            release_side(st);
+            fx_set_error("fx fork: creating the second stream failed: %s", hipGetErrorString(e));
+            return nullptr;
+        }
+    }
+    if ((e = hipEventRecord(st.fork_ev, stream)) != hipSuccess ||
+        (e = hipStreamWaitEvent(st.side, st.fork_ev, 0)) != hipSuccess) {
+        fx_set_error("fx fork: %s", hipGetErrorString(e));
+        return nullptr;
+    }
+    return st.side;
+}
+
+int FxCallGuard::join()
+{
+    StreamState &st = *static_cast<StreamState *>(state);
+    FX_HIP_CHECK(hipEventRecord(st.join_ev, st.side));
+    FX_HIP_CHECK(hipStreamWaitEvent(stream, st.join_ev, 0));
+    return FX_OK;
+}
+
+FxProfileScope::FxProfileScope(hipStream_t s, int64_t units, int pair) : stream(s), active(g_profile), pair(pair)
 {
     if (!active)
         return;
-    if (!g_ev0) {
-        if (hipEventCreate(&g_ev0) != hipSuccess || hipEventCreate(&g_ev1) != hipSuccess) {
+    if (!g_ev[pair][0]) {
+        if (hipEventCreate(&g_ev[pair][0]) != hipSuccess || hipEventCreate(&g_ev[pair][1]) != hipSuccess) {
+            g_ev[pair][0] = nullptr;
             active = false;
             return;
         }
     }
-    g_ev_valid = false;
-    if (hipEventRecord(g_ev0, stream) != hipSuccess)
+    if (pair == 0) {
+        g_prof_units = units;
+        g_ev_valid[1] = false;
+    }
+    g_ev_valid[pair] = false;
+    if (hipEventRecord(g_ev[pair][0], stream) != hipSuccess)
         active = false;
 }
 
@@ -167,8 +229,8 @@ FxProfileScope::~FxProfileScope()
 {
     if (!active)
         return;
-    if (hipEventRecord(g_ev1, stream) == hipSuccess)
-        g_ev_valid = true;
+    if (hipEventRecord(g_ev[pair][1], stream) == hipSuccess)
+        g_ev_valid[pair] = true;
 }
 
 extern "C" {
@@ -204,6 +266,10 @@ int fx_shutdown(void)
         std::lock_guard<std::mutex> call(st.call_mu);
         bool synced = false;
         release_pin(st);
+        if (st.side) {
+            (void)hipSetDevice(kv.first.first);
+            release_side(st);
+        }
         for (int s = 0; s < kScratchSlots; s++) {
             if (!st.scratch[s])
                 continue;
@@ -228,6 +294,7 @@ int fx_release_stream(void *stream)
         return FX_OK;
     std::lock_guard<std::mutex> call(st->call_mu);
     release_pin(*st);
+    release_side(*st);
     for (int s = 0; s < kScratchSlots; s++) {
         if (st->scratch[s])
             FX_HIP_CHECK(hipFreeAsync(st->scratch[s], (hipStream_t)stream));
@@ -247,16 +314,25 @@ int fx_profile(int enable)
     return FX_OK;
 }
 
+long long fx_profile_last_units(void) { return (long long)g_prof_units; }
+
 double fx_profile_last_ms(void)
 {
-    if (!g_ev_valid)
+    if (!g_ev_valid[0])
         return -1.0;
-    if (hipEventSynchronize(g_ev1) != hipSuccess)
-        return -1.0;
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, g_ev0, g_ev1) != hipSuccess)
-        return -1.0;
-    return (double)ms;
+    double sum = 0.0;
+    int n = 0;
+    for (int pair = 0; pair < 2; pair++) {
+        if (!g_ev_valid[pair])
+            continue;
+        float ms = 0.f;
+        if (hipEventSynchronize(g_ev[pair][1]) != hipSuccess ||
+            hipEventElapsedTime(&ms, g_ev[pair][0], g_ev[pair][1]) != hipSuccess)
+            return -1.0;
+        sum += (double)ms;
+        n++;
+    }
+    return sum / n;
 }
 
 }  // extern "C"

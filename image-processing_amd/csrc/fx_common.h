@@ -37,6 +37,12 @@ struct FxCallGuard {
     // after them).  NULL (and the error text set) on failure.
     void *staging(size_t bytes);
     int staged();
+    // A second stream of the call's own, for work that may run beside what the call enqueues on `stream`.
+    // fork() makes it wait for everything enqueued on `stream` so far and returns it (NULL and the error text
+    // set on failure); join() makes `stream` wait for everything enqueued on it since.  Scratch of the call may
+    // be used on both between the two.  The stream is created on first use and kept with the stream's scratch.
+    hipStream_t fork();
+    int join();
 };
 
 // Defined beside the block it looks up (fx_hu.hip); fx_init calls it so that
@@ -46,7 +52,11 @@ int fx_hu_noalloc_setup(void);
 struct FxProfileScope {
     hipStream_t stream;
     bool active;
-    explicit FxProfileScope(hipStream_t s);
+    int pair;
+    // units: how many of the call's units the launch in the scope processes (0: all of them).  pair 1 brackets a
+    // second launch of the same kernel that runs beside the first on another stream (opened after pair 0's
+    // scope): fx_profile_last_ms then reports the mean of the two.
+    explicit FxProfileScope(hipStream_t s, int64_t units = 0, int pair = 0);
     ~FxProfileScope();
 };
 

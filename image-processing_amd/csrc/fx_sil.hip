@@ -1852,9 +1852,6 @@ int sil_batch(const uint8_t *d_img, int64_t B, int H, int W, int64_t pitch, int6
     }
 
     const int64_t px = (int64_t)H * W;
-    int64_t chunk = (int64_t)(1ll << 31) / px;   // blurred copies of a chunk: at most 2 GiB of scratch
-    chunk = chunk < 1 ? 1 : (chunk > 65536 ? 65536 : chunk);
-    chunk = chunk > B ? B : chunk;
     const int rows = H > resolution ? H : resolution;
     const int side = W > resolution ? W : resolution;
     const int wpr = (side + 31) / 32;
@@ -1876,6 +1873,14 @@ int sil_batch(const uint8_t *d_img, int64_t B, int H, int W, int64_t pitch, int6
             grid = cus * per_cu;
         grid = grid > 4096 ? 4096 : grid;
     }
+    // A large batch runs as two halves on two streams: one half's Otsu chains (a few hundred waves, each a
+    // serial chain), and the ends of its blur and mask launches, leave most of the device idle, and the other
+    // half's kernels fill it.  Each half still gives every resident mask block several views.
+    const int lanes = B >= 4 * (int64_t)grid ? 2 : 1;
+    const int64_t per_lane = (B + lanes - 1) / lanes;
+    int64_t chunk = (int64_t)(1ll << 31) / px;   // blurred copies of a chunk: at most 2 GiB of scratch per half
+    chunk = chunk < 1 ? 1 : (chunk > 65536 ? 65536 : chunk);
+    chunk = chunk > per_lane ? per_lane : chunk;
 
     const size_t blur_bytes = sil_align((size_t)chunk * px);
     const size_t hist_bytes = sil_align((size_t)chunk * 256 * sizeof(uint32_t));
@@ -1883,7 +1888,8 @@ int sil_batch(const uint8_t *d_img, int64_t B, int H, int W, int64_t pitch, int6
     const size_t runs_bytes = sil_align((size_t)run_blocks * 2 * run_cap * sizeof(uint32_t));
     const size_t level_bytes = sil_align((size_t)chunk * sizeof(int32_t));
     FxCallGuard guard(stream);
-    unsigned char *base = (unsigned char *)guard.scratch(blur_bytes + hist_bytes + runs_bytes + level_bytes, 3);
+    const size_t lane_bytes = blur_bytes + hist_bytes + runs_bytes + level_bytes;
+    unsigned char *base = (unsigned char *)guard.scratch(lanes * lane_bytes, 3);
     if (!base)
         return FX_ENOMEM;
 
@@ -1942,39 +1948,62 @@ int sil_batch(const uint8_t *d_img, int64_t B, int H, int W, int64_t pitch, int6
                                                                : (const void *)sil_mask_kernel<false>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)mask_lds));
 
-    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
-        const int64_t nb = B - b0 < chunk ? B - b0 : chunk;
-        A.img = d_img + b0 * stride;
-        A.B = nb;
-        A.mask = d_mask ? d_mask + b0 * (int64_t)resolution * resolution : nullptr;
-        A.partial = d_partial ? d_partial + b0 * 30 : nullptr;
-        A.info = d_info ? d_info + b0 * 8 : nullptr;
-        FX_HIP_CHECK(hipMemsetAsync(A.hist, 0, (size_t)nb * 256 * sizeof(uint32_t), stream));
-        const dim3 bgrid((unsigned)((H + tr - 1) / tr), (unsigned)nb);
-        if (mode == FX_SIL_OPENCV) {
-            if (aligned)
-                hipLaunchKernelGGL(sil_blur_cv_kernel<true>, bgrid, dim3(FX_BLOCK), blur_lds, stream, A);
-            else
-                hipLaunchKernelGGL(sil_blur_cv_kernel<false>, bgrid, dim3(FX_BLOCK), blur_lds, stream, A);
-            hipLaunchKernelGGL(sil_otsu_cv_kernel, dim3((unsigned)((nb + FX_WAVE - 1) / FX_WAVE)), dim3(FX_WAVE), otsu_lds,
-                               stream, (const uint32_t *)A.hist, nb, 1.0 / (double)((int64_t)W * H), A.level);
-        } else if (aligned) {
-            hipLaunchKernelGGL(sil_blur_kernel<true>, bgrid, dim3(FX_BLOCK), blur_lds, stream, A);
-        } else {
-            hipLaunchKernelGGL(sil_blur_kernel<false>, bgrid, dim3(FX_BLOCK), blur_lds, stream, A);
+    hipStream_t lane_stream[2] = {stream, nullptr};
+    if (lanes == 2 && !(lane_stream[1] = guard.fork()))
+        return FX_EHIP;
+    // chunk k of both halves is enqueued before chunk k + 1 of either: the halves start together
+    const int rc = [&]() -> int {
+    for (int64_t c0 = 0; c0 < per_lane; c0 += chunk) {
+        for (int lane = 0; lane < lanes; lane++) {
+            const int64_t b0 = lane * per_lane + c0;
+            const int64_t lane_end = (lane + 1) * per_lane < B ? (lane + 1) * per_lane : B;
+            if (b0 >= lane_end)
+                continue;
+            const int64_t nb = lane_end - b0 < chunk ? lane_end - b0 : chunk;
+            const hipStream_t s = lane_stream[lane];
+            unsigned char *lb = base + lane * lane_bytes;
+            A.blur = lb;
+            A.hist = (uint32_t *)(lb + blur_bytes);
+            A.runs = (uint32_t *)(lb + blur_bytes + hist_bytes);
+            A.level = (int32_t *)(lb + blur_bytes + hist_bytes + runs_bytes);
+            A.img = d_img + b0 * stride;
+            A.B = nb;
+            A.mask = d_mask ? d_mask + b0 * (int64_t)resolution * resolution : nullptr;
+            A.partial = d_partial ? d_partial + b0 * 30 : nullptr;
+            A.info = d_info ? d_info + b0 * 8 : nullptr;
+            FX_HIP_CHECK(hipMemsetAsync(A.hist, 0, (size_t)nb * 256 * sizeof(uint32_t), s));
+            const dim3 bgrid((unsigned)((H + tr - 1) / tr), (unsigned)nb);
+            if (mode == FX_SIL_OPENCV) {
+                if (aligned)
+                    hipLaunchKernelGGL(sil_blur_cv_kernel<true>, bgrid, dim3(FX_BLOCK), blur_lds, s, A);
+                else
+                    hipLaunchKernelGGL(sil_blur_cv_kernel<false>, bgrid, dim3(FX_BLOCK), blur_lds, s, A);
+                hipLaunchKernelGGL(sil_otsu_cv_kernel, dim3((unsigned)((nb + FX_WAVE - 1) / FX_WAVE)), dim3(FX_WAVE),
+                                   otsu_lds, s, A.hist, nb, 1.0 / (double)px, A.level);
+            } else if (aligned) {
+                hipLaunchKernelGGL(sil_blur_kernel<true>, bgrid, dim3(FX_BLOCK), blur_lds, s, A);
+            } else {
+                hipLaunchKernelGGL(sil_blur_kernel<false>, bgrid, dim3(FX_BLOCK), blur_lds, s, A);
+            }
+            FX_HIP_CHECK(hipGetLastError());
+            const int g = (int)(nb < grid ? nb : grid);  // persistent blocks: as many as are resident at once
+            {
+                // the longest of the kernels; each half's last chunk is what stays
+                FxProfileScope prof(s, nb == B ? 0 : nb, lane);
+                if (mode == FX_SIL_OPENCV)
+                    hipLaunchKernelGGL(sil_mask_kernel<true>, dim3(g), dim3(FX_BLOCK), mask_lds, s, A);
+                else
+                    hipLaunchKernelGGL(sil_mask_kernel<false>, dim3(g), dim3(FX_BLOCK), mask_lds, s, A);
+            }
+            FX_HIP_CHECK(hipGetLastError());
         }
-        FX_HIP_CHECK(hipGetLastError());
-        const int g = (int)(nb < grid ? nb : grid);  // persistent blocks: as many as are resident at once
-        {
-            FxProfileScope prof(stream);  // the longer of the two kernels; the last chunk's launch is what stays
-            if (mode == FX_SIL_OPENCV)
-                hipLaunchKernelGGL(sil_mask_kernel<true>, dim3(g), dim3(FX_BLOCK), mask_lds, stream, A);
-            else
-                hipLaunchKernelGGL(sil_mask_kernel<false>, dim3(g), dim3(FX_BLOCK), mask_lds, stream, A);
-        }
-        FX_HIP_CHECK(hipGetLastError());
     }
     return FX_OK;
+    }();
+    // also after a failed launch: what the second stream did get must not outlive the call's place in `stream`
+    if (lanes == 2 && guard.join() != FX_OK && rc == FX_OK)
+        return FX_EHIP;
+    return rc;
 }
 
 }  // namespace

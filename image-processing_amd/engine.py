@@ -479,3 +479,9 @@ def profile_last_ms() -> float:
     """Milliseconds the kernels of the last hu_batch / pca_batch call took
     (waits for them); negative when profiling was off."""
     return float(_lib.load().fx_profile_last_ms())
+
+
+def profile_last_units() -> int:
+    """Units the launch timed by profile_last_ms processed, when the call split its units over several launches of
+    that kernel; 0 when the launch processed all of the call's units."""
+    return int(_lib.load().fx_profile_last_units())

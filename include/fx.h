@@ -435,10 +435,16 @@ int fx_synth_points_f32(float *d_pts, int64_t B, int64_t N, uint64_t seed,
  * fx_pca_batch_f32 call when profiling is switched on (fx_profile(1)): the
  * library then brackets that call's launches with HIP events on `stream`.
  * fx_profile_last_ms waits for the events.  Returns < 0 when nothing was
- * recorded.
+ * recorded.  A call that splits its units over several launches of its
+ * dominant kernel (the silhouette stage runs large batches as two halves
+ * side by side on two streams) brackets one launch per half and reports the
+ * mean of the two durations: fx_profile_last_units is the number of units
+ * one such launch processed, 0 when a single launch processed all the
+ * call's units.
  */
 int fx_profile(int enable);
 double fx_profile_last_ms(void);
+long long fx_profile_last_units(void);
 
 #ifdef __cplusplus
 }

@@ -189,10 +189,11 @@ def test_rejects_unsupported_sizes(gpu):
 
 
 def test_large_batch_is_deterministic_and_chunked(gpu, oracle, backend):
-    """More views than one internal chunk of blurred scratch holds at 512x512."""
+    """More views than two internal chunks of blurred scratch hold at 512x512 (a batch this large runs as two
+    halves, each in chunks of its own)."""
     rng = np.random.default_rng(21)
     base = np.stack([gray_scene(rng, 512, 512, dark_object=bool(k & 1)) for k in range(8)])
-    reps = 1100                                           # 8800 views x 256 KiB > 2 GiB
+    reps = 2100                                           # 16800 views x 256 KiB > 2 x 2 GiB
     d = torch.from_numpy(base).to(gpu).repeat(reps, 1, 1)
     eng = pkg("engine")
     out = eng.silhouette_batch(d, 224, 0.05, True, backend=backend)["mask"]
@@ -201,6 +202,35 @@ def test_large_batch_is_deterministic_and_chunked(gpu, oracle, backend):
     for k in range(8):
         np.testing.assert_array_equal(first[k], oracle_silhouette(oracle, base[k], 224, 0.05, True)[0])
     assert torch.equal(out.view(reps, 8, 224, 224), out[:8].unsqueeze(0).expand(reps, -1, -1, -1))
+
+
+def test_two_halves_on_two_streams_equal_small_batches(gpu, backend):
+    """A batch large enough to run as two halves (one on the caller's stream, one on a second stream the library
+    keeps for it) gives every view the mask and the moments it gets in a small batch: on the default stream, and on
+    a stream of the caller's own that is released afterwards.  The odd count leaves the halves unequal."""
+    rng = np.random.default_rng(33)
+    base = np.stack([gray_scene(rng, 224, 224, dark_object=bool(k & 1)) for k in range(16)])
+    eng = pkg("engine")
+    small = eng.silhouette_hu_batch(torch.from_numpy(base).to(gpu), 224, 0.05, True, mask=True, info=True,
+                                    backend=backend)
+    reps, B = 1251, 16 * 1251 - 5
+    d = torch.from_numpy(base).to(gpu).repeat(reps, 1, 1)[:B].contiguous()
+    torch.cuda.synchronize()
+    own = torch.cuda.Stream(device=gpu)
+    for stream in (None, own):
+        with torch.cuda.stream(stream):
+            big = eng.silhouette_hu_batch(d, 224, 0.05, True, mask=True, info=True, backend=backend)
+            # enqueued behind the call on the same stream: must see the second half's results too
+            tail = big["hulog7"][-11:].clone()
+        torch.cuda.synchronize()
+        for key in ("mask", "info", "hulog7"):
+            want = small[key].repeat(reps, *([1] * (small[key].dim() - 1)))[:B]
+            assert torch.equal(big[key], want), key
+        assert torch.equal(tail, big["hulog7"][-11:])
+    pkg("_lib").call("fx_release_stream", int(own.cuda_stream))
+    again = eng.silhouette_hu_batch(d, 224, 0.05, True, backend=backend)["hulog7"]   # the default stream's own still works
+    torch.cuda.synchronize()
+    assert torch.equal(again, big["hulog7"])
 
 
 # ------------------------------------------------------------ gray fit (pad_and_resize)

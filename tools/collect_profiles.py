@@ -16,7 +16,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 DOMINANT = {"c3": "hu_band_kernel", "c2": "hu_band_kernel", "c4": "pca_sets_full_kernel", "c5": "hu_band_kernel",
             "f1": "sil_mask_kernel", "p1": "render_views_kernel"}
-UNITS = {"c3": (125000, 262144), "c2": (100000, 65536), "c4": (1000000, 12288), "c5": (64, 67108864), "f1": (20000, 50176),
+UNITS = {"c3": (125000, 262144), "c2": (100000, 65536), "c4": (1000000, 12288), "c5": (64, 67108864), "f1": (10000, 50176),
          "p1": (2000, 12288)}
 # FETCH_SIZE on gfx950 tallies the 128-byte requests of a 16 B/lane coalesced stream at 64 bytes, i.e. half the
 # bytes; other request mixes are uncalibrated.  The factor is applied only to kernels whose loads are all
