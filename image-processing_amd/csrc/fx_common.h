@@ -85,6 +85,21 @@ typedef unsigned long long u64;
 typedef long long i64;
 
 __device__ __forceinline__ int fx_lane() { return threadIdx.x & (FX_WAVE - 1); }
+
+// 16 bytes of an input that the launch reads exactly once: a non-temporal load (global_load_dwordx4 ... nt), so
+// the stream does not displace what the caches hold for re-use.  p must be 16-byte aligned.
+__device__ __forceinline__ uint4 fx_load_once16(const void *p)
+{
+    typedef uint32_t fx_u32x4 __attribute__((ext_vector_type(4)));
+    const fx_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const fx_u32x4 *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float4 fx_load_once_f4(const float4 *p)
+{
+    typedef float fx_f32x4 __attribute__((ext_vector_type(4)));
+    const fx_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const fx_f32x4 *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ int fx_wave() { return threadIdx.x >> 6; }
 
 // Butterfly all-reduce over the 64 lanes of a wave: every lane ends with the

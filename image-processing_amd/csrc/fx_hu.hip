@@ -403,7 +403,7 @@ __device__ __forceinline__ void hu_image_body(const HuArgs &A, const int64_t b, 
             if (y < H) {
                 const uint8_t *p = img + (int64_t)y * A.pitch + x0;
                 if (full) {
-                    v = *reinterpret_cast<const uint4 *>(p);
+                    v = fx_load_once16(p);
                 } else {
                     uint32_t w[4] = {0, 0, 0, 0};
                     int n = W - x0;
@@ -902,7 +902,7 @@ __global__ __launch_bounds__(FX_BLOCK, FX_BAND_WAVES) void hu_band_kernel(HuArgs
         if (ALIGNED) {
             const int yc = valid ? y : 0;
             const int xc = active ? x0 : 0;
-            uint4 v = *reinterpret_cast<const uint4 *>(img + (int64_t)yc * A.pitch + xc);
+            uint4 v = fx_load_once16(img + (int64_t)yc * A.pitch + xc);
             v.x = valid ? v.x : 0u;
             v.y = valid ? v.y : 0u;
             v.z = valid ? v.z : 0u;
