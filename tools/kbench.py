@@ -102,6 +102,15 @@ if __name__ == "__main__":
         for (B,H,W,c) in [(7500,1024,1024,False),(7500,1024,1024,True),(30000,512,512,True),(60000,512,256,True)]:
             ms, gbps = time_hu(B,H,W,c)
             print(f"hu B={B} {H}x{W} contour={c}: {ms:.3f} ms  {gbps:.0f} GB/s", flush=True)
+    elif what == "hulds":
+        for (B,H,W,c) in [(60000,512,512,True),(60000,512,512,False),(100000,256,256,True)]:
+            ms, gbps = time_hu(B,H,W,c)
+            print(f"hu B={B} {H}x{W} contour={c}: {ms:.3f} ms  {gbps:.0f} GB/s", flush=True)
+    elif what == "hufoot":   # footprint and contour work against the streaming rate
+        for (B,H,W,c) in [(125000,512,512,False),(125000,512,512,True),(16000,512,512,False),(16000,512,512,True),(500,8192,8192//16,False),(2000,2048,2048,False),(8000,1024,1024,False),(8000,1024,1024,True)]:
+            ms, gbps = time_hu(B,H,W,c)
+            print(f"hu B={B} {H}x{W} contour={c}: {ms:.3f} ms  {gbps:.0f} GB/s", flush=True)
+            torch.cuda.empty_cache()
     elif what == "hu":
         for (B,H,W,c) in [(30000,512,512,False),(30000,512,512,True),(100000,256,256,False),(100000,256,256,True)]:
             ms, gbps = time_hu(B,H,W,c)
