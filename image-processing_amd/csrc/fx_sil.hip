@@ -482,14 +482,21 @@ __global__ __launch_bounds__(FX_BLOCK) void sil_blur_cv_kernel(SilArgs A)
 // level to level in double, so the 256 steps are a serial chain of roundings;
 // a lane per image runs it, 64 histograms staged through LDS per block.
 constexpr int SIL_OTSU_PITCH = 257;
-__global__ __launch_bounds__(FX_WAVE) void sil_otsu_cv_kernel(const uint32_t *hist, int64_t B, double scale, int32_t *level)
+__global__ __launch_bounds__(FX_BLOCK) void sil_otsu_cv_kernel(const uint32_t *hist, int64_t B, double scale, int32_t *level)
 {
     extern __shared__ __align__(16) uint8_t sil_smem[];
     uint32_t *h = (uint32_t *)sil_smem;  // [64][257]
     const int64_t b0 = (int64_t)blockIdx.x * FX_WAVE;
     const int n = B - b0 < FX_WAVE ? (int)(B - b0) : FX_WAVE;
-    for (int i = threadIdx.x; i < n * 256; i += FX_WAVE)
-        h[(i >> 8) * SIL_OTSU_PITCH + (i & 255)] = hist[b0 * 256 + i];
+    // all four waves stage the 64 histograms (16 bytes per load, every round's loads in flight together); the
+    // first wave then runs the chains
+    const uint4 *src = (const uint4 *)(hist + b0 * 256);
+#pragma unroll 4
+    for (int i = threadIdx.x; i < n * 64; i += FX_BLOCK) {
+        const uint4 q = src[i];
+        uint32_t *dst = h + (i >> 6) * SIL_OTSU_PITCH + 4 * (i & 63);
+        dst[0] = q.x, dst[1] = q.y, dst[2] = q.z, dst[3] = q.w;
+    }
     __syncthreads();
     if ((int)threadIdx.x >= n)
         return;
@@ -1978,7 +1985,7 @@ int sil_batch(const uint8_t *d_img, int64_t B, int H, int W, int64_t pitch, int6
                     hipLaunchKernelGGL(sil_blur_cv_kernel<true>, bgrid, dim3(FX_BLOCK), blur_lds, s, A);
                 else
                     hipLaunchKernelGGL(sil_blur_cv_kernel<false>, bgrid, dim3(FX_BLOCK), blur_lds, s, A);
-                hipLaunchKernelGGL(sil_otsu_cv_kernel, dim3((unsigned)((nb + FX_WAVE - 1) / FX_WAVE)), dim3(FX_WAVE),
+                hipLaunchKernelGGL(sil_otsu_cv_kernel, dim3((unsigned)((nb + FX_WAVE - 1) / FX_WAVE)), dim3(FX_BLOCK),
                                    otsu_lds, s, A.hist, nb, 1.0 / (double)px, A.level);
             } else if (aligned) {
                 hipLaunchKernelGGL(sil_blur_kernel<true>, bgrid, dim3(FX_BLOCK), blur_lds, s, A);

@@ -4,7 +4,7 @@
 out=gpurun_out/silprof
 rm -rf $out; mkdir -p $out
 export TMPDIR=/tmp
-timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 tools/siltime.py 20000 > $out.log 2>&1
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 tools/siltime.py ${1:-20000} > $out.log 2>&1
 python3 - "$out" <<'PY'
 import csv, sys
 from pathlib import Path
