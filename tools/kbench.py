@@ -102,6 +102,11 @@ if __name__ == "__main__":
         for (B,H,W,c) in [(7500,1024,1024,False),(7500,1024,1024,True),(30000,512,512,True),(60000,512,256,True)]:
             ms, gbps = time_hu(B,H,W,c)
             print(f"hu B={B} {H}x{W} contour={c}: {ms:.3f} ms  {gbps:.0f} GB/s", flush=True)
+    elif what == "husmall":   # small images: block tails against streaming
+        for (B,H,W,c) in [(200000,224,224,False),(200000,224,224,True),(400000,128,128,False),(100000,256,256,False),(100000,256,256,True),(60000,512,512,False)]:
+            ms, gbps = time_hu(B,H,W,c)
+            print(f"hu B={B} {H}x{W} contour={c}: {ms:.3f} ms  {gbps:.0f} GB/s", flush=True)
+            torch.cuda.empty_cache()
     elif what == "hulds":
         for (B,H,W,c) in [(60000,512,512,True),(60000,512,512,False),(100000,256,256,True)]:
             ms, gbps = time_hu(B,H,W,c)
