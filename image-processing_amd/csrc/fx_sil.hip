@@ -755,6 +755,16 @@ struct SilRuns {
 // of neighbouring rows that touch (sharing a column, or for CONN8 also
 // diagonally) are united lock-free, then every run is pointed at its root.
 // Every thread of the block calls this; the result is block-uniform.
+// Inlined into the kernel on purpose.  As a called function (what the compiler chooses when left alone) it made
+// hipcc 7.2 park a caller-saved register around the call with a copy placed ahead of the `s_or_b64 exec` that
+// re-enables the lanes which sat out the loop in front of the call: those lanes kept a stale copy, and from a
+// block's second view on they addressed the histogram in LDS through it.  SIL_REPRO_MISCOMPILE rebuilds that
+// variant (tools/isa_lint.py reports it; `make lint-selftest` checks that it still does).
+#ifdef SIL_REPRO_MISCOMPILE
+__attribute__((noinline))
+#else
+__forceinline__
+#endif
 __device__ SilRuns sil_label(const uint32_t *m, int rows, int wc, SilDiv dv, int wpr, bool conn8, uint32_t *pre, uint32_t *s_scan,
                              int *s_nruns, uint32_t *lds_runs, uint32_t *glob_runs, int run_cap)
 {
@@ -1036,11 +1046,13 @@ __global__ __launch_bounds__(FX_BLOCK, 5) void sil_mask_kernel(SilArgs A)
     for (int64_t b = blockIdx.x; b < A.B; b += gridDim.x) {
         // The thread index is made opaque once per view: what is derived from it (addresses into the LDS arrays and
         // the scratch buffers) is then computed where it is used instead of being kept -- and, at 96 registers,
-        // spilled -- across the whole loop over the views.
+        // spilled -- across the whole loop over the views.  This is for speed only (5 %); results do not depend on it.
         int t = t_block;
-        asm volatile("" : "+v"(t));
         unsigned long long zero64 = 0ull;   // (likewise: a 64-bit zero hoisted out of the loop ends up spilled)
+#ifndef SIL_REPRO_MISCOMPILE
+        asm volatile("" : "+v"(t));
         asm volatile("" : "+v"(zero64));
+#endif
         __syncthreads();
         // ---- Otsu level (reference :101-126): float64 in the reference's order
         if (!CV)

@@ -204,6 +204,37 @@ def test_large_batch_is_deterministic_and_chunked(gpu, oracle, backend):
     assert torch.equal(out.view(reps, 8, 224, 224), out[:8].unsqueeze(0).expand(reps, -1, -1, -1))
 
 
+@pytest.mark.parametrize("shape", [(512, 512, 224, 3072), (200, 152, 160, 6000), (224, 224, 224, 9000)])
+def test_later_rounds_of_a_persistent_block(gpu, oracle, backend, shape):
+    """A mask block works through many views in turn and keeps what it derives from its thread index across them.
+    Every view of a batch of several rounds per block must equal the result its image gets alone, and those the
+    oracle's: the case that exposed a register clobbered between a block's first and second view (the compiler
+    had placed a copy ahead of the lane-mask restore in front of a call; the build now checks the assembly for it)."""
+    H, W, res, B = shape
+    rng = np.random.default_rng(77)
+    nbase = 12
+    base = np.stack([gray_scene(rng, H, W, dark_object=bool(k & 1), blobs=2 + k % 4) for k in range(nbase)])
+    base[3] = rng.integers(0, 256, (H, W), dtype=np.uint8)          # noise: thousands of runs, no dominant component
+    base[7, H // 4:H // 2, W // 4:W // 2] = 128                      # a flat patch
+    want = [oracle_silhouette(oracle, img, res, 0.05, True, None) for img in base]
+    eng = pkg("engine")
+    order = torch.from_numpy(rng.integers(0, nbase, B)).to(gpu)      # a different image per round of a block
+    d = torch.from_numpy(base).to(gpu)[order].contiguous()
+    for _ in range(2):
+        r = eng.silhouette_batch(d, res, 0.05, True, info=True, backend=backend)
+        torch.cuda.synchronize()
+        masks, info = r["mask"], r["info"]
+        for k in range(nbase):
+            sel = (order == k).nonzero().flatten()
+            assert len(sel) > 0
+            wm = torch.from_numpy(np.array(want[k][0])).to(gpu)
+            wi = torch.from_numpy(np.asarray(want[k][1], dtype=np.int32)).to(gpu)
+            bad_i = (info[sel] != wi).any(1).nonzero().flatten()
+            assert bad_i.numel() == 0, f"image {k}: info differs in views {sel[bad_i][:8].tolist()} (Otsu level, flags, crop)"
+            bad_m = (masks[sel] != wm).flatten(1).any(1).nonzero().flatten()
+            assert bad_m.numel() == 0, f"image {k}: mask differs in views {sel[bad_m][:8].tolist()}"
+
+
 def test_two_halves_on_two_streams_equal_small_batches(gpu, backend):
     """A batch large enough to run as two halves (one on the caller's stream, one on a second stream the library
     keeps for it) gives every view the mask and the moments it gets in a small batch: on the default stream, and on
