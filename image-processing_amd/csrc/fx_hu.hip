@@ -12,6 +12,7 @@
 // the in-chunk power sums, 32-bit per-lane partials flushed into 64-bit ones,
 // wave shuffles + LDS for the block reduction.  No MFMA.
 #include "fx_common.h"
+#include <atomic>
 #include "fx_eig.h"
 #include <mutex>
 #include <stdlib.h>
@@ -1592,7 +1593,7 @@ static __device__ __align__(256) unsigned char g_hu_noalloc_scratch[HU_NOALLOC_B
 
 constexpr int HU_NOALLOC_MAX_DEVICES = 16;
 std::mutex g_hu_noalloc_mu;
-unsigned char *g_hu_noalloc_ptr[HU_NOALLOC_MAX_DEVICES] = {};
+std::atomic<unsigned char *> g_hu_noalloc_ptr[HU_NOALLOC_MAX_DEVICES] = {};   // written once under the mutex
 
 }  // namespace
 
@@ -1603,12 +1604,12 @@ int fx_hu_noalloc_setup(void)
     FX_HIP_CHECK(hipGetDevice(&dev));
     FX_REQUIRE(dev >= 0 && dev < HU_NOALLOC_MAX_DEVICES, "fx_hu_batch_u8_noalloc: device %d out of range", dev);
     std::lock_guard<std::mutex> lk(g_hu_noalloc_mu);
-    if (g_hu_noalloc_ptr[dev])
+    if (g_hu_noalloc_ptr[dev].load(std::memory_order_acquire))
         return FX_OK;
     unsigned char *ptr = nullptr;
     FX_HIP_CHECK(hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(g_hu_noalloc_scratch)));
     FX_REQUIRE(ptr != nullptr, "fx_hu_batch_u8_noalloc: the built-in scratch block has no address on device %d", dev);
-    g_hu_noalloc_ptr[dev] = ptr;
+    g_hu_noalloc_ptr[dev].store(ptr, std::memory_order_release);
     return FX_OK;
 }
 
@@ -1623,12 +1624,17 @@ extern "C" int fx_hu_batch_u8_noalloc(const uint8_t *d_img, int64_t B, int H, in
     int dev = -1;
     FX_HIP_CHECK(hipGetDevice(&dev));
     FX_REQUIRE(dev >= 0 && dev < HU_NOALLOC_MAX_DEVICES, "fx_hu_batch_u8_noalloc: device %d out of range", dev);
-    if (!g_hu_noalloc_ptr[dev]) {
+    if (!g_hu_noalloc_ptr[dev].load(std::memory_order_acquire)) {
+        // the address lookup is not a stream operation: it must not run while the caller's stream is capturing
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (stream && hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+            FX_REQUIRE(false, "fx_hu_batch_u8_noalloc: fx_init(%d) has to run before the first call under stream capture", dev);
         const int rc = fx_hu_noalloc_setup();
         if (rc != FX_OK)
             return rc;
     }
-    const HuScratch scratch = {nullptr, g_hu_noalloc_ptr[dev], HU_NOALLOC_BYTES, "fx_hu_batch_u8_noalloc"};
+    const HuScratch scratch = {nullptr, g_hu_noalloc_ptr[dev].load(std::memory_order_acquire), HU_NOALLOC_BYTES,
+                               "fx_hu_batch_u8_noalloc"};
     return hu_batch_impl("fx_hu_batch_u8_noalloc", scratch, d_img, B, H, W, pitch_bytes, img_stride_bytes, thresh,
                          on_value, d_moments24, d_hu7, d_hulog7, n_bins, d_cpca, d_ceig, (hipStream_t)stream);
 }

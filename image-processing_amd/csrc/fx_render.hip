@@ -143,7 +143,9 @@ __global__ __launch_bounds__(RENDER_THREADS) void render_views_kernel(RenderArgs
     // one after the other otherwise.
     const int K = A.K, half = K / 2, KK = K * K;
     const int lane = fx_lane(), wave = fx_wave();
-    const int G = FX_WAVE / KK;                      // stamps per step
+    // stamps per step: as many as the lanes hold, but no more than KK + 1 -- lane (grp, cell) checks stamp grp
+    // against the earlier stamp number `cell`, and cell only runs to KK - 1 (a 1 x 1 marker: two per step)
+    const int G = FX_WAVE / KK < KK + 1 ? FX_WAVE / KK : KK + 1;
     const int grp = lane / KK, cell = lane - grp * KK;
     const bool lane_used = grp < G;
     const int cell_dy = cell / K - half, cell_dx = cell % K - half;
@@ -197,6 +199,10 @@ __global__ __launch_bounds__(RENDER_THREADS) void render_views_kernel(RenderArgs
             const int cnt = __popcll(todo);
             if (take)
                 my_list[__builtin_amdgcn_mbcnt_hi((unsigned int)(todo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)todo, 0u))] = mine;
+            // the list is written by the lanes that hold a point and read by others of the same wave
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             for (int g0 = 0; g0 < cnt; g0 += G) {
                 const bool live = lane_used && g0 + grp < cnt;
                 const uint32_t rc = live ? my_list[g0 + grp] : 0u;

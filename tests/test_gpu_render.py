@@ -41,7 +41,9 @@ def test_batches_against_oracle(gpu, oracle):
         clouds.append(((rng.normal(size=(n, 3)) * np.exp(rng.uniform(-2, 1, size=3))) @ q.T + rng.normal(size=3) * 3).astype(np.float32))
     clouds.append(np.tile(np.array([[0.5, -1.0, 2.0]], dtype=np.float32), (30, 1)))
     clouds.append(np.c_[np.linspace(-1, 1, 200), np.zeros(200), np.zeros(200)].astype(np.float32))
-    for res, ps, views in ((224, 2.0, 12), (96, 5.0, 4), (384, 1.0, 3), (512, 2.0, 2), (700, 4.0, 2)):   # the last two: banded canvas
+    # (0.5: a 1 x 1 stamp, where coinciding points of one step must still blend one after the other;
+    # the last two: banded canvas)
+    for res, ps, views in ((224, 2.0, 12), (224, 0.5, 3), (96, 5.0, 4), (384, 1.0, 3), (512, 2.0, 2), (700, 4.0, 2)):
         got = rv.render_views_batch(clouds, views, res, ps).cpu().numpy()
         assert got.shape == (len(clouds), views, res, res)
         stamp = rv.marker_stamp(ps)
