@@ -35,6 +35,8 @@ SIGNATURES = {
     "fx_hu_groupstat": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
     "fx_pca_batch_f32": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_int, c_int, c_int,
                                  c_void_p, c_void_p, c_void_p]),
+    "fx_pca_batch_f64": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_int, c_int, c_int,
+                                 c_void_p, c_void_p, c_void_p]),
     "fx_silhouette_batch_u8": (c_int, [c_void_p, c_i64, c_int, c_int, c_i64, c_i64, c_int, ctypes.c_double, c_int,
                                        c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "fx_silhouette_moments_batch_u8": (c_int, [c_void_p, c_i64, c_int, c_int, c_i64, c_i64, c_int, ctypes.c_double,

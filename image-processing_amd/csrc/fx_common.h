@@ -180,6 +180,31 @@ __device__ __forceinline__ double fx_wave_max_f64_dpp(double v)
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// Wave-wide sum of doubles through DPP row operations (the lanes a step does not write take 0): partners in
+// pairs, quads, half rows and rows of 16, then the rows' totals passed on; every lane receives lane 63's total.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double fx_dpp_f64_z(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = (int)b, hi = (int)(b >> 32);
+    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return __longlong_as_double(((long long)hi2 << 32) | (unsigned int)lo2);
+}
+__device__ __forceinline__ double fx_wave_sum_f64_dpp(double v)
+{
+    v += fx_dpp_f64_z<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+    v += fx_dpp_f64_z<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+    v += fx_dpp_f64_z<0x141, 0xf>(v);   // row_half_mirror
+    v += fx_dpp_f64_z<0x140, 0xf>(v);   // row_mirror
+    v += fx_dpp_f64_z<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v += fx_dpp_f64_z<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
+    const long long b = __double_as_longlong(v);
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)b, 63);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // Wave-wide maximum of unsigned integers.  The lanes a DPP step does not write take 0, the identity of the
 // maximum, so move and maximum fold into one DPP instruction per step.
 __device__ __forceinline__ uint32_t fx_wave_max_u32_dpp(uint32_t v)

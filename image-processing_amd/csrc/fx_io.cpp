@@ -152,10 +152,17 @@ int read_one_points(const char *path, int64_t want_rows, float *out, int64_t *ro
                     for (int c = 0; c < 3; c++)
                         out[r * 3 + c] = s[r * h.cols + c];
             } else {
+                // float64 samples are taken over only when float32 holds every one of them exactly (the reference
+                // evaluates the float64 values); other files are left to the caller, who keeps them wide
                 const double *s = (const double *)tmp.data();
-                for (int64_t r = 0; r < h.rows; r++)
-                    for (int c = 0; c < 3; c++)
-                        out[r * 3 + c] = (float)s[r * h.cols + c];  // round to nearest even, as astype does
+                for (int64_t r = 0; r < h.rows && st == FX_IO_OK; r++)
+                    for (int c = 0; c < 3; c++) {
+                        const double v = s[r * h.cols + c];
+                        const float f = (float)v;
+                        if (!((double)f == v) && v == v)   // (NaN stays NaN either way)
+                            st = FX_IO_EWIDE;
+                        out[r * 3 + c] = f;
+                    }
             }
         }
     }

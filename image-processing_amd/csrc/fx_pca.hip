@@ -17,9 +17,10 @@
 // is computed by one wave per block, a lane per set, or by the 16 lanes of a
 // set's row.
 //
-// Large clouds: cut into chunks of 16384 points, one launch per pass (sum,
-// centred second moments, projection maximum, histogram) with a block per
-// chunk; a CSR batch is sorted into the lists of the kernels on the device.
+// Large clouds, and every set of a float64 batch: cut into chunks of 8192
+// points that a persistent launch works through twice (sums; projections +
+// histogram), see the section on large clouds below; a CSR batch is sorted into
+// the lists of the kernels on the device.
 #include "fx_common.h"
 #include "fx_eig.h"
 #include <stdlib.h>
@@ -29,6 +30,7 @@ namespace {
 
 struct PcaArgs {
     const float *pts;
+    const double *pts64;     // float64 input (fx_pca_batch_f64): the points, and pts is NULL
     const int64_t *offsets;  // device, B+1 entries, or NULL
     const int32_t *set_ids;  // device list of the sets this launch handles, or NULL = all
     int64_t n_sets;          // number of sets this launch handles
@@ -42,6 +44,7 @@ struct PcaArgs {
     const int32_t *n_sets_dev;  // when set: the number of entries of set_ids, known on the device only
     int32_t *redo_list;         // pca_sets_full_kernel: sets left to pca_sets_redo_kernel, and their number
     int32_t *redo_count;
+    int redo_zeroed;            // host side: *redo_count is zero already (no memset ahead of the launch)
 };
 
 constexpr int HIST_MAX = 64;
@@ -1259,65 +1262,204 @@ __global__ __launch_bounds__(FX_WAVE *NW, 3) void pca_sets_quad_kernel(PcaArgs A
 }
 
 // ---------------------------------------------------------------- large sets
-// Clouds that do not fit a wave's LDS slab are cut into chunks of CLOUD_CHUNK
-// points; every pass over the data is one launch with one block per chunk, so
-// a 4M-point cloud spreads over 256 blocks instead of serialising on one, and
-// a batch of unequal clouds is balanced at chunk granularity.  Partial results
-// go to a per-chunk record; the next launch's blocks combine the records of
-// their own cloud (in a fixed tree order: results do not depend on scheduling).
-constexpr int CLOUD_CHUNK = 16384;
-constexpr int CLOUD_THREADS = 256;
+// ---------------------------------------------------------------------------
+// Large clouds (more points than a wave keeps in registers; with float64 input: every set).
+//
+// A cloud is cut into chunks of CLOUD_CHUNK points, a block per chunk and pass, so a 4M-point cloud spreads over
+// the whole chip and a batch of unequal clouds balances at chunk granularity.  One launch per step:
+//   sum      sums of d = p - pivot and of d d^T over the chunk (pivot = the cloud's first point, as in the set
+//            kernels: the mean need not be known before the second moments are summed), and the chunk's bounding box
+//   state    once per cloud: chunk records combined in a fixed order -> mean, covariance -> eigen-solve -> the
+//            nine scalars and the first principal axis; from the box, a bound U on |projection|
+//   proj     |projection on the axis| of every point: its maximum over the cloud, and for every point a 16-bit
+//            code floor(65536 |projection| / U), written to scratch
+//   hist     bins between 0 and that maximum from the codes: a code pins its point's projection down to U / 65536,
+//            which decides the bin for all but the few points next to a bin edge -- those are read and projected
+//            again
+//   finish   the row's histogram part from the counts
+// (with `normalize` a pass for the largest distance from the mean comes between sum and the eigen-solve).
+// A point is read twice, 12 bytes each time, and its code written and read once, 2 bytes: the third pass over the
+// points that the bins would otherwise need -- their range is only known when every projection has been seen -- is
+// a pass over a sixth of the bytes.  The passes walk the chunk list in alternating directions: what a pass read
+// last, a good part of the 256 MiB Infinity Cache, is what the next one reads first.
+// ---------------------------------------------------------------------------
+#ifndef FX_CLOUD_CHUNK
+#define FX_CLOUD_CHUNK 8192
+#endif
+#ifndef FX_CLOUD_THREADS
+#define FX_CLOUD_THREADS 256
+#endif
+#ifndef FX_CLOUD_BATCH
+#define FX_CLOUD_BATCH 4
+#endif
+constexpr int CLOUD_CHUNK = FX_CLOUD_CHUNK;
+constexpr int CLOUD_THREADS = FX_CLOUD_THREADS;
 constexpr int CLOUD_WAVES = CLOUD_THREADS / FX_WAVE;
-// per-chunk record, doubles: 0-2 sums of p - pivot, 3 max r^2, 4-9 sums of (p - pivot)(p - pivot)^T, 10 max |projection|
-constexpr int PART = 12;
-// per-cloud record, doubles: 0-2 mean, 3 rmax (0 = no scaling), 4-6 first principal axis
-constexpr int STATE = 8;
+constexpr int CLOUD_BATCH = FX_CLOUD_BATCH;   // groups of four points a thread has in flight
+// per-chunk record, doubles: 0-2 sums of d, 3-8 sums of d d^T, 9-11 the smallest and 12-14 the largest coordinates
+constexpr int PART = 16;
+// per-cloud record, doubles: 0-2 mean, 3 rmax (0 = no scaling), 4-6 first principal axis, 7 the bound U on
+// |projection| (after scaling), 8-13 second moments about the mean, 14-19 bounding box (smallest, largest)
+constexpr int STATE = 20;
+constexpr int CLOUD_HIST_COPIES = 4, CLOUD_HIST_PITCH = HIST_MAX + 1;   // LDS histograms per wave (lane mod 4), bank-skewed
+constexpr double CLOUD_CODES = 65536.0;
+static_assert(CLOUD_CHUNK % (8 * CLOUD_THREADS) == 0, "a chunk's codes are moved 16 bytes per thread and round");
+
+struct CloudCtl {
+    u64 top_bits;   // largest |projection| (the bits of that double >= 0, which order as it does)
+    u64 r2_bits;    // normalize: largest squared distance from the mean
+    u64 hist[HIST_MAX];
+};
+
+// What a pass needs to know about a chunk, in one 32-byte read.
+struct __align__(16) CloudChunk {
+    int64_t base;      // the cloud's first point, counted in points from the start of the batch
+    int64_t i0;        // the chunk's first point within the cloud
+    int32_t count;     // points in the chunk
+    int32_t cloud;     // position in cloud_ids of the chunk's cloud
+    int32_t pad[2];
+};
 
 struct CloudWork {
-    const int32_t *cloud_ids;    // [n_clouds] set index of every large cloud
+    const int32_t *cloud_ids;    // [n_clouds] set index of every cloud
     const int32_t *cloud_first;  // [n_clouds + 1] first chunk of every cloud
-    const int32_t *chunk_cloud;  // [n_chunks] position in cloud_ids of the chunk's cloud
+    const CloudChunk *chunks;    // [n_chunks]
     double *part;                // [n_chunks][PART]
-    uint32_t *hpart;             // [n_chunks][HIST_MAX]
+    CloudCtl *ctl;               // [n_clouds], zero at the start of a call
     double *state;               // [n_clouds][STATE]
-    // device-built work lists (ragged batches classified on the device): the counts live in device memory
-    // and the launches use a fixed grid whose blocks loop; NULL = the grid is the list
-    const int32_t *n_chunks_dev;
+    uint16_t *codes;             // [n_chunks][CLOUD_CHUNK]
+    const int32_t *n_chunks_dev; // list lengths (device memory)
     const int32_t *n_clouds_dev;
 };
 
+template <typename T>
 struct ChunkView {
-    const float *g;   // first point of the cloud
+    const T *g;       // first point of the cloud
     int64_t n;        // points in the cloud
     int64_t i0, i1;   // this chunk's point range
     int64_t set;
     int cloud, first, nch;
 };
 
-__device__ __forceinline__ ChunkView chunk_view(const PcaArgs &A, const CloudWork &Wk, int c)
+template <typename T>
+__device__ __forceinline__ const T *cloud_points(const PcaArgs &A)
 {
-    ChunkView v;
-    v.cloud = Wk.chunk_cloud[c];
-    v.set = Wk.cloud_ids[v.cloud];
-    v.first = Wk.cloud_first[v.cloud];
-    v.nch = Wk.cloud_first[v.cloud + 1] - v.first;
+    return sizeof(T) == 8 ? reinterpret_cast<const T *>(A.pts64) : reinterpret_cast<const T *>(A.pts);
+}
+
+template <typename T>
+__device__ __forceinline__ ChunkView<T> cloud_view(const PcaArgs &A, const CloudWork &Wk, int cloud)
+{
+    ChunkView<T> v;
+    v.cloud = cloud;
+    v.set = Wk.cloud_ids[cloud];
+    v.first = Wk.cloud_first[cloud];
+    v.nch = Wk.cloud_first[cloud + 1] - v.first;
     if (A.offsets) {
         const int64_t a = A.offsets[v.set];
         v.n = A.offsets[v.set + 1] - a;
-        v.g = A.pts + a * A.dims;
+        v.g = cloud_points<T>(A) + a * A.dims;
     } else {
         v.n = A.N;
-        v.g = A.pts + v.set * A.N * A.dims;
+        v.g = cloud_points<T>(A) + v.set * A.N * A.dims;
     }
-    v.i0 = (int64_t)(c - v.first) * CLOUD_CHUNK;
-    v.i1 = v.i0 + CLOUD_CHUNK < v.n ? v.i0 + CLOUD_CHUNK : v.n;
+    v.i0 = 0;
+    v.i1 = v.n;
     return v;
 }
 
+// (what the passes over the chunks use: g, i0, i1, cloud)
+template <typename T>
+__device__ __forceinline__ ChunkView<T> chunk_view(const PcaArgs &A, const CloudWork &Wk, int c)
+{
+    const CloudChunk d = Wk.chunks[c];
+    ChunkView<T> v;
+    v.g = cloud_points<T>(A) + d.base * A.dims;
+    v.n = 0;
+    v.i0 = d.i0;
+    v.i1 = d.i0 + d.count;
+    v.set = 0;
+    v.cloud = d.cloud;
+    v.first = 0;
+    v.nch = 0;
+    return v;
+}
+
+struct CloudPoint {
+    double x, y, z;
+};
+template <typename T>
+__device__ __forceinline__ CloudPoint cloud_point(const T *g, int64_t i, int dims)
+{
+    CloudPoint p;
+    p.x = (double)g[i * dims];
+    p.y = (double)g[i * dims + 1];
+    p.z = dims == 3 ? (double)g[i * dims + 2] : 0.0;
+    return p;
+}
+
+// Calls f(k, x, y, z) for every point of the chunk, k = its index within the chunk.  float32 3-D points, the
+// usual case: where the chunk's floats are 16-byte aligned a thread takes four consecutive points with three
+// 16-byte loads, several such groups at a time; the up to three points before the first aligned one and
+// after the last whole group, and every other layout, are read one by one.
+template <typename T, typename F>
+__device__ __forceinline__ void cloud_for_points(const PcaArgs &A, const ChunkView<T> &v, F f)
+{
+    const int dims = A.dims;
+    const int t = threadIdx.x;
+    if (sizeof(T) == 4 && dims == 3) {
+        const float *g = reinterpret_cast<const float *>(v.g);
+        int64_t ib = v.i0;
+        for (int k = 0; k < 4 && ib < v.i1 && ((uintptr_t)(g + ib * 3) & 15u); k++)
+            ib++;
+        const int ng = (int)((v.i1 - ib) / 4);
+        const int64_t ie = ib + 4 * (int64_t)ng;
+        for (int64_t i = v.i0 + t; i < ib; i += CLOUD_THREADS) {
+            const CloudPoint p = cloud_point(g, i, 3);
+            f((int)(i - v.i0), p.x, p.y, p.z);
+        }
+        const float4 *g4 = reinterpret_cast<const float4 *>(g + ib * 3);
+        // CLOUD_BATCH groups at a time: all their loads are out before the arithmetic of the first starts (a
+        // round trip to memory costs far more than a group's arithmetic)
+#pragma unroll 1
+        for (int g0 = t; g0 < ng; g0 += CLOUD_BATCH * CLOUD_THREADS) {
+            float4 a[CLOUD_BATCH], b[CLOUD_BATCH], c[CLOUD_BATCH];
+#pragma unroll
+            for (int j = 0; j < CLOUD_BATCH; j++) {
+                const int gi = g0 + j * CLOUD_THREADS < ng ? g0 + j * CLOUD_THREADS : g0;   // (beyond the end: group g0 again, unused)
+                a[j] = g4[3 * gi];
+                b[j] = g4[3 * gi + 1];
+                c[j] = g4[3 * gi + 2];
+            }
+#pragma unroll
+            for (int j = 0; j < CLOUD_BATCH; j++) {
+                const int gi = g0 + j * CLOUD_THREADS;
+                if (gi < ng) {
+                    const int k = (int)(ib - v.i0) + 4 * gi;
+                    f(k, (double)a[j].x, (double)a[j].y, (double)a[j].z);
+                    f(k + 1, (double)a[j].w, (double)b[j].x, (double)b[j].y);
+                    f(k + 2, (double)b[j].z, (double)b[j].w, (double)c[j].x);
+                    f(k + 3, (double)c[j].y, (double)c[j].z, (double)c[j].w);
+                }
+            }
+        }
+        for (int64_t i = ie + t; i < v.i1; i += CLOUD_THREADS) {
+            const CloudPoint p = cloud_point(g, i, 3);
+            f((int)(i - v.i0), p.x, p.y, p.z);
+        }
+    } else {
+        for (int64_t i = v.i0 + t; i < v.i1; i += CLOUD_THREADS) {
+            const CloudPoint p = cloud_point(v.g, i, dims);
+            f((int)(i - v.i0), p.x, p.y, p.z);
+        }
+    }
+}
+
+// Block-wide sum / maximum in a fixed order: waves by butterfly, then the waves' results one after the other.
 template <bool MAX>
 __device__ __forceinline__ double cloud_block_reduce(double v, double *red)
 {
-    v = MAX ? fx_wave_max_f64(v) : fx_wave_sum_f64(v);
+    v = MAX ? fx_wave_max_f64_dpp(v) : fx_wave_sum_f64_dpp(v);
     if (fx_lane() == 0)
         red[fx_wave()] = v;
     __syncthreads();
@@ -1329,84 +1471,17 @@ __device__ __forceinline__ double cloud_block_reduce(double v, double *red)
     return s;
 }
 
-// Combines field k of the records of chunks first .. first+nch-1; every thread gets the result.
-template <bool MAX>
-__device__ __forceinline__ double cloud_combine(const double *part, int first, int nch, int k, double *red)
-{
-    double v = 0.0;
-    for (int i = threadIdx.x; i < nch; i += CLOUD_THREADS) {
-        const double p = part[(int64_t)(first + i) * PART + k];
-        v = MAX ? fmax(v, p) : v + p;
-    }
-    return cloud_block_reduce<MAX>(v, red);
-}
+// ---- step bodies (every thread of a block runs them)
 
-struct CloudPoint {
-    double x, y, z;
-};
-__device__ __forceinline__ CloudPoint cloud_point(const float *g, int64_t i, int dims)
+// sum: the chunk's record
+template <typename T>
+__device__ __forceinline__ void cloud_sum_step(const PcaArgs &A, const CloudWork &Wk, const ChunkView<T> &v, int chunk,
+                                               double *red)
 {
-    // (three 4-byte loads per point: a wave's 64 lanes then cover 768 contiguous bytes three times; one 12-byte
-    // load per lane was 20 % slower over the whole chain)
-    CloudPoint p;
-    p.x = (double)g[i * dims];
-    p.y = (double)g[i * dims + 1];
-    p.z = dims == 3 ? (double)g[i * dims + 2] : 0.0;
-    return p;
-}
-
-// Calls f(x, y, z) for every point of the chunk.  Where the chunk's floats are 16-byte aligned a thread takes
-// four consecutive points with three (2-D: two) 16-byte loads -- a wave then reads 3 KB of contiguous memory per
-// round, as the set kernels do -- and only the up to three points before the first aligned one and after the
-// last whole group are read one by one.
-template <typename F>
-__device__ __forceinline__ void cloud_for_points(const PcaArgs &A, const ChunkView &v, F f)
-{
-    const int dims = A.dims;
-    int64_t ib = v.i0;
-    for (int k = 0; k < 4 && ib < v.i1 && ((uintptr_t)(v.g + ib * dims) & 15u); k++)
-        ib++;
-    if ((uintptr_t)(v.g + ib * dims) & 15u)
-        ib = v.i1;   // (2-D points at an odd float offset never reach alignment: all one by one)
-    const int64_t ng = (v.i1 - ib) / 4, ie = ib + 4 * ng;
-    for (int64_t i = v.i0 + threadIdx.x; i < ib; i += CLOUD_THREADS) {
-        const CloudPoint p = cloud_point(v.g, i, dims);
-        f(p.x, p.y, p.z);
-    }
-    if (dims == 3) {
-        const float4 *g4 = reinterpret_cast<const float4 *>(v.g + ib * 3);
-        for (int64_t g = threadIdx.x; g < ng; g += CLOUD_THREADS) {
-            const float4 a = g4[3 * g], b = g4[3 * g + 1], c = g4[3 * g + 2];
-            f((double)a.x, (double)a.y, (double)a.z);
-            f((double)a.w, (double)b.x, (double)b.y);
-            f((double)b.z, (double)b.w, (double)c.x);
-            f((double)c.y, (double)c.z, (double)c.w);
-        }
-    } else {
-        const float4 *g4 = reinterpret_cast<const float4 *>(v.g + ib * 2);
-        for (int64_t g = threadIdx.x; g < ng; g += CLOUD_THREADS) {
-            const float4 a = g4[2 * g], b = g4[2 * g + 1];
-            f((double)a.x, (double)a.y, 0.0);
-            f((double)a.z, (double)a.w, 0.0);
-            f((double)b.x, (double)b.y, 0.0);
-            f((double)b.z, (double)b.w, 0.0);
-        }
-    }
-    for (int64_t i = ie + threadIdx.x; i < v.i1; i += CLOUD_THREADS) {
-        const CloudPoint p = cloud_point(v.g, i, dims);
-        f(p.x, p.y, p.z);
-    }
-}
-
-// First pass: sums of d = p - pivot and of d d^T over the chunk, the pivot being the cloud's first point (as in
-// the set kernels: mean = pivot + sum d / n, centred second moments = sum d d^T - (sum d)(sum d)^T / n, so the
-// mean does not have to be known before the second moments are summed and one pass over the cloud is saved).
-__device__ __forceinline__ void cloud_sum_body(const PcaArgs &A, const CloudWork &Wk, const int chunk, double *red)
-{
-    const ChunkView v = chunk_view(A, Wk, chunk);
     const CloudPoint k = cloud_point(v.g, 0, A.dims);
     double a9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    cloud_for_points(A, v, [&](double px, double py, double pz) {
+    double lo[3] = {k.x, k.y, k.z}, hi[3] = {k.x, k.y, k.z};   // (the pivot lies in the cloud's box anyway)
+    cloud_for_points(A, v, [&](int, double px, double py, double pz) {
         const double dx = px - k.x, dy = py - k.y, dz = pz - k.z;
         a9[0] += dx;
         a9[1] += dy;
@@ -1417,59 +1492,148 @@ __device__ __forceinline__ void cloud_sum_body(const PcaArgs &A, const CloudWork
         a9[6] = fma(dy, dy, a9[6]);
         a9[7] = fma(dy, dz, a9[7]);
         a9[8] = fma(dz, dz, a9[8]);
+        lo[0] = fmin(lo[0], px), hi[0] = fmax(hi[0], px);
+        lo[1] = fmin(lo[1], py), hi[1] = fmax(hi[1], py);
+        lo[2] = fmin(lo[2], pz), hi[2] = fmax(hi[2], pz);
     });
-    double *out = Wk.part + (int64_t)chunk * PART;
+    // fifteen block results behind one pair of barriers: red[q][wave]
 #pragma unroll
-    for (int q = 0; q < 9; q++) {
-        const double tot = cloud_block_reduce<false>(a9[q], red);
-        if (threadIdx.x == 0)
-            out[q < 3 ? q : q + 1] = tot;   // fields 0-2 and 4-9; field 3 is the largest r^2
+    for (int q = 0; q < 15; q++) {
+        const double w = q < 9 ? fx_wave_sum_f64_dpp(a9[q]) : q < 12 ? -fx_wave_max_f64_dpp(-lo[q - 9]) : fx_wave_max_f64_dpp(hi[q - 12]);
+        if (fx_lane() == 0)
+            red[q * CLOUD_WAVES + fx_wave()] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < 15) {
+        const int q = threadIdx.x;
+        double s = red[q * CLOUD_WAVES];
+#pragma unroll
+        for (int w = 1; w < CLOUD_WAVES; w++) {
+            const double r = red[q * CLOUD_WAVES + w];
+            s = q < 9 ? s + r : q < 12 ? fmin(s, r) : fmax(s, r);
+        }
+        Wk.part[(int64_t)chunk * PART + q] = s;
+    }
+    __syncthreads();
+}
+
+// state: the chunk records of a cloud combined (record i goes to slot i mod 256, a slot adds its records in
+// order, the slots are added as cloud_block_reduce does), mean and second moments about it; then, unless the
+// scale is still to come (normalize, first call), the eigen-solve, the head of the row and the bound on the
+// projections.
+// (Out of line: one lane per cloud runs it, and inlined its registers would be the streaming loops' registers.)
+__device__ __attribute__((noinline)) void cloud_state_solve(float *out_row, double *eig_row, double *st, int64_t n, double rmax)
+{
+    double S[6];
+    const bool scale = rmax > 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const double m = st[8 + k];
+        S[k] = scale ? m / (rmax * rmax) : m;   // moments of the points divided by rmax
+    }
+    double head[9], lam[3], v1[3];
+    cov_to_head(S, n, head, lam, v1);
+    // |sum_i (p_i - m_i) a_i| <= sum_i max(|lo_i - m_i|, |hi_i - m_i|) |a_i|, a little more for the rounding of
+    // either side
+    double bound = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        bound += fmax(fabs(st[14 + k] - st[k]), fabs(st[17 + k] - st[k])) * fabs(v1[k]);
+    if (scale)
+        bound /= rmax;
+    bound = bound * (1.0 + 1e-9) + 1e-300;
+    st[3] = scale ? rmax : 0.0;
+    st[4] = v1[0];
+    st[5] = v1[1];
+    st[6] = v1[2];
+    st[7] = bound;
+    for (int k = 0; k < 9; k++)
+        out_row[k] = (float)head[k];
+    if (eig_row) {
+        for (int k = 0; k < 3; k++) {
+            eig_row[k] = lam[k];
+            eig_row[3 + k] = v1[k];
+        }
     }
 }
 
-// What every block of a cloud derives from the combined chunk records: mean, covariance sums about the mean.
-struct CloudMoments {
-    double mx, my, mz;
-    double S[6];
-};
-__device__ __forceinline__ CloudMoments cloud_moments(const PcaArgs &A, const CloudWork &Wk, const ChunkView &v, double *red)
+template <typename T>
+__device__ __forceinline__ void cloud_state_step(const PcaArgs &A, const CloudWork &Wk, const ChunkView<T> &v, bool scaled,
+                                                 double *red)
 {
-    const CloudPoint k = cloud_point(v.g, 0, A.dims);
-    const double dn = (double)v.n;
-    double t[9];
+    double *st = Wk.state + (int64_t)v.cloud * STATE;
+    if (!scaled) {
+        double t9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const double inf = __longlong_as_double(0x7ff0000000000000LL);
+        double lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf};
+        if (threadIdx.x < 256)
+            for (int i = threadIdx.x; i < v.nch; i += 256) {
+                const double *rec = Wk.part + (int64_t)(v.first + i) * PART;
+                double r[15];
 #pragma unroll
-    for (int q = 0; q < 9; q++)
-        t[q] = cloud_combine<false>(Wk.part, v.first, v.nch, q < 3 ? q : q + 1, red);
-    const double ox = t[0] / dn, oy = t[1] / dn, oz = t[2] / dn;   // mean - pivot
-    CloudMoments m;
-    m.mx = k.x + ox, m.my = k.y + oy, m.mz = k.z + oz;
-    m.S[0] = fma(-t[0], ox, t[3]);
-    m.S[1] = fma(-t[0], oy, t[4]);
-    m.S[2] = fma(-t[0], oz, t[5]);
-    m.S[3] = fma(-t[1], oy, t[6]);
-    m.S[4] = fma(-t[1], oz, t[7]);
-    m.S[5] = fma(-t[2], oz, t[8]);
-    return m;
+                for (int q = 0; q < 15; q++)   // (the loads of a record are out together)
+                    r[q] = rec[q];
+#pragma unroll
+                for (int q = 0; q < 9; q++)
+                    t9[q] += r[q];
+#pragma unroll
+                for (int q = 0; q < 3; q++)
+                    lo[q] = fmin(lo[q], r[9 + q]), hi[q] = fmax(hi[q], r[12 + q]);
+            }
+#pragma unroll
+        for (int q = 0; q < 15; q++) {
+            const double w = q < 9 ? fx_wave_sum_f64_dpp(t9[q]) : q < 12 ? -fx_wave_max_f64_dpp(-lo[q - 9]) : fx_wave_max_f64_dpp(hi[q - 12]);
+            if (fx_lane() == 0)
+                red[q * CLOUD_WAVES + fx_wave()] = w;
+        }
+        __syncthreads();
+        double box[6];
+#pragma unroll
+        for (int q = 0; q < 15; q++) {
+            double s = red[q * CLOUD_WAVES];
+#pragma unroll
+            for (int w = 1; w < CLOUD_WAVES; w++) {
+                const double r = red[q * CLOUD_WAVES + w];
+                s = q < 9 ? s + r : q < 12 ? fmin(s, r) : fmax(s, r);
+            }
+            if (q < 9)
+                t9[q] = s;
+            else
+                box[q - 9] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const CloudPoint k = cloud_point(v.g, 0, A.dims);
+            const double dn = (double)v.n;
+            const double ox = t9[0] / dn, oy = t9[1] / dn, oz = t9[2] / dn;   // mean - pivot
+            st[0] = k.x + ox;
+            st[1] = k.y + oy;
+            st[2] = k.z + oz;
+            st[3] = 0.0;
+            st[8] = fma(-t9[0], ox, t9[3]);
+            st[9] = fma(-t9[0], oy, t9[4]);
+            st[10] = fma(-t9[0], oz, t9[5]);
+            st[11] = fma(-t9[1], oy, t9[6]);
+            st[12] = fma(-t9[1], oz, t9[7]);
+            st[13] = fma(-t9[2], oz, t9[8]);
+#pragma unroll
+            for (int q = 0; q < 6; q++)
+                st[14 + q] = box[q];
+        }
+        if (A.normalize)
+            return;
+    }
+    if (threadIdx.x == 0) {
+        double rmax = 0.0;
+        if (scaled)
+            rmax = sqrt(__longlong_as_double((long long)Wk.ctl[v.cloud].r2_bits));
+        cloud_state_solve(A.out + v.set * (9 + A.n_bins), A.eig ? A.eig + v.set * 6 : (double *)nullptr, st, v.n, rmax);
+    }
 }
 
-// normalize only: the largest r^2 of the centred points of the chunk
-__device__ __forceinline__ void cloud_rmax_body(const PcaArgs &A, const CloudWork &Wk, const int chunk, double *red)
+__device__ __forceinline__ double cloud_projection(double px, double py, double pz, const double *st)
 {
-    const ChunkView v = chunk_view(A, Wk, chunk);
-    const CloudMoments m = cloud_moments(A, Wk, v, red);
-    double r2 = 0.0;
-    cloud_for_points(A, v, [&](double px, double py, double pz) {
-        const double dx = px - m.mx, dy = py - m.my, dz = pz - m.mz;
-        r2 = fmax(r2, dx * dx + dy * dy + dz * dz);
-    });
-    r2 = cloud_block_reduce<true>(r2, red);
-    if (threadIdx.x == 0)
-        Wk.part[(int64_t)chunk * PART + 3] = r2;
-}
-
-__device__ __forceinline__ double cloud_projection(const CloudPoint &p, const double *st)
-{
-    double dx = p.x - st[0], dy = p.y - st[1], dz = p.z - st[2];
+    double dx = px - st[0], dy = py - st[1], dz = pz - st[2];
     if (st[3] > 0.0) {
         dx /= st[3];
         dy /= st[3];
@@ -1478,171 +1642,234 @@ __device__ __forceinline__ double cloud_projection(const CloudPoint &p, const do
     return fabs(fma(dz, st[6], fma(dy, st[5], dx * st[4])));
 }
 
-// Covariance -> eigen-solve (every block of the cloud repeats it: a few hundred
-// instructions) -> largest |projection| of the chunk.  The cloud's first block
-// also writes the nine scalars and the axis.
-__device__ __forceinline__ void cloud_proj_body(const PcaArgs &A, const CloudWork &Wk, const int chunk, double *red)
+// normalize: the largest squared distance from the mean over the chunk, into the cloud's record
+template <typename T>
+__device__ __forceinline__ void cloud_rmax_step(const PcaArgs &A, const CloudWork &Wk, const ChunkView<T> &v, double *red)
 {
-    const ChunkView v = chunk_view(A, Wk, chunk);
-    const CloudMoments m = cloud_moments(A, Wk, v, red);
-    double rmax = 0.0;
-    if (A.normalize)
-        rmax = sqrt(cloud_combine<true>(Wk.part, v.first, v.nch, 3, red));
-    const bool scale = A.normalize && rmax > 0.0;
-    double S[6];
-#pragma unroll
-    for (int k = 0; k < 6; k++)
-        S[k] = scale ? m.S[k] / (rmax * rmax) : m.S[k];   // moments of the points divided by rmax
-    double head[9], lam[3], v1[3];
-    cov_to_head(S, v.n, head, lam, v1);
-    double st[STATE];
-    st[0] = m.mx;
-    st[1] = m.my;
-    st[2] = m.mz;
-    st[3] = scale ? rmax : 0.0;
-    st[4] = v1[0];
-    st[5] = v1[1];
-    st[6] = v1[2];
-    double top = 0.0;
-    cloud_for_points(A, v, [&](double px, double py, double pz) {
-        CloudPoint p;
-        p.x = px, p.y = py, p.z = pz;
-        top = fmax(top, cloud_projection(p, st));
+    const double *st = Wk.state + (int64_t)v.cloud * STATE;
+    const double mx = st[0], my = st[1], mz = st[2];
+    double r2 = 0.0;
+    cloud_for_points(A, v, [&](int, double px, double py, double pz) {
+        const double dx = px - mx, dy = py - my, dz = pz - mz;
+        r2 = fmax(r2, dx * dx + dy * dy + dz * dz);
     });
-    top = cloud_block_reduce<true>(top, red);
-    if (threadIdx.x == 0) {
-        Wk.part[(int64_t)chunk * PART + 10] = top;
-        if (chunk == v.first) {
-            const int width = 9 + A.n_bins;
-            for (int k = 0; k < 9; k++)
-                A.out[v.set * width + k] = (float)head[k];
-            if (A.eig) {
-                for (int k = 0; k < 3; k++) {
-                    A.eig[v.set * 6 + k] = lam[k];
-                    A.eig[v.set * 6 + 3 + k] = v1[k];
-                }
-            }
-        }
-    }
-    // the axis goes to the cloud record for the histogram pass; every block of
-    // the cloud computed the same values, the first one stores them
-    if (threadIdx.x == 0 && chunk == v.first) {
-        double *wst = Wk.state + (int64_t)v.cloud * STATE;
-#pragma unroll
-        for (int k = 0; k < 7; k++)
-            wst[k] = st[k];
-    }
+    r2 = cloud_block_reduce<true>(r2, red);
+    if (threadIdx.x == 0)
+        atomicMax(&Wk.ctl[v.cloud].r2_bits, (u64)__double_as_longlong(r2));
 }
 
-__device__ __forceinline__ void cloud_hist_body(const PcaArgs &A, const CloudWork &Wk, const int chunk, double *red, uint32_t *hist)
+// proj: |projection| of the chunk's points -- the chunk's maximum into the cloud's record, the points' codes
+// (staged in LDS, so that they leave in 16-byte stores) into the chunk's stretch of the code array
+template <typename T>
+__device__ __forceinline__ void cloud_proj_step(const PcaArgs &A, const CloudWork &Wk, const ChunkView<T> &v, int chunk,
+                                                const double *st, uint16_t *stage, double *red)
 {
-    const ChunkView v = chunk_view(A, Wk, chunk);
-    if (threadIdx.x < HIST_MAX)
-        hist[threadIdx.x] = 0;
-    const double top = cloud_combine<true>(Wk.part, v.first, v.nch, 10, red);  // its barriers cover the zeroing
-    double st[STATE];
-    const double *gs = Wk.state + (int64_t)v.cloud * STATE;
+    const double to_code = CLOUD_CODES / st[7];
+    double top = 0.0;
+    cloud_for_points(A, v, [&](int k, double px, double py, double pz) {
+        const double pr = cloud_projection(px, py, pz, st);
+        const int c = (int)(pr * to_code);   // (pr <= the bound: at most 65536, up to rounding)
+        stage[k] = (uint16_t)(c > 65535 ? 65535 : c);
+        top = fmax(top, pr);
+    });
+    top = cloud_block_reduce<true>(top, red);   // (its barriers also order the staging before the copy)
+    if (threadIdx.x == 0)
+        atomicMax(&Wk.ctl[v.cloud].top_bits, (u64)__double_as_longlong(top));
+    const uint4 *from = reinterpret_cast<const uint4 *>(stage);
+    uint4 *to = reinterpret_cast<uint4 *>(Wk.codes + (int64_t)chunk * CLOUD_CHUNK);
+    const int words = ((int)(v.i1 - v.i0) + 7) / 8;
+    for (int k = threadIdx.x; k < words; k += CLOUD_THREADS)
+        to[k] = from[k];
+    __syncthreads();
+}
+
+// hist: bins of the chunk's projections against the cloud's maximum, from the codes.  Code c says that the
+// projection lies in [c, c + 1) U / 65536 (give or take the rounding of one multiplication); where both ends of
+// that stretch, widened by a thousandth of itself, fall into the same bin, that is the point's bin -- and the
+// exact projection is at least that margin away from any bin edge, so the rule of fx_hist_bin gives the same.
+// The other points (two codes or so per bin edge) are read and projected again.  Counting: up to eight bins, a
+// thread counts its (few) points in eight 8-bit fields of a register and the wave adds its lanes' fields up --
+// most points share a few bins, and lanes adding to one LDS word take turns; more bins: LDS, a few copies per
+// wave.
+constexpr int CLOUD_CODE_ROUNDS = CLOUD_CHUNK / (8 * CLOUD_THREADS);
+struct CloudCodes {
+    uint4 w[CLOUD_CODE_ROUNDS];
+};
+// a thread's share of the chunk's codes (all of the chunk's stretch of the array: the caller need not know yet
+// how many points the chunk has)
+__device__ __forceinline__ CloudCodes cloud_load_codes(const CloudWork &Wk, int chunk)
+{
+    const uint4 *codes = reinterpret_cast<const uint4 *>(Wk.codes + (int64_t)chunk * CLOUD_CHUNK);
+    CloudCodes c;
 #pragma unroll
-    for (int k = 0; k < 7; k++)
-        st[k] = gs[k];
+    for (int r = 0; r < CLOUD_CODE_ROUNDS; r++)
+        c.w[r] = codes[r * CLOUD_THREADS + threadIdx.x];
+    return c;
+}
+
+template <typename T>
+__device__ __forceinline__ void cloud_hist_step(const PcaArgs &A, const CloudWork &Wk, const ChunkView<T> &v, const CloudCodes &codes,
+                                                const double *st, double top, uint32_t (*hist)[CLOUD_HIST_PITCH])
+{
+    static_assert(CLOUD_CHUNK / CLOUD_THREADS <= 255, "a thread's points must fit an 8-bit count");
     const int nb = A.n_bins;
+    for (int k = threadIdx.x; k < CLOUD_WAVES * CLOUD_HIST_COPIES * CLOUD_HIST_PITCH; k += CLOUD_THREADS)
+        (&hist[0][0])[k] = 0u;
+    __syncthreads();
     if (top > 0.0) {
         const double step = top / (double)nb;
         const double inv_step = (double)nb / top;
-        cloud_for_points(A, v, [&](double px, double py, double pz) {
-            CloudPoint p;
-            p.x = px, p.y = py, p.z = pz;
-            atomicAdd(&hist[fx_hist_bin(cloud_projection(p, st), step, inv_step, nb)], 1u);
-        });
+        const double code_to_bin = inv_step * (st[7] / CLOUD_CODES);
+        uint32_t *mine = hist[fx_wave() * CLOUD_HIST_COPIES + (fx_lane() & (CLOUD_HIST_COPIES - 1))];
+        const bool packed = nb <= 8;
+        u64 fields = 0ull;
+        const int cnt = (int)(v.i1 - v.i0);
+        const auto count = [&](int bin) {
+            if (packed)
+                fields += 1ull << (8 * bin);
+            else
+                atomicAdd(&mine[bin], 1u);
+        };
+        static_assert(8 * CLOUD_CODE_ROUNDS <= 32, "one bit per code of a thread");
+        uint32_t again = 0u;   // this thread's points that are to be projected again
+#pragma unroll
+        for (int r = 0; r < CLOUD_CODE_ROUNDS; r++) {
+            const int at = r * CLOUD_THREADS + threadIdx.x;
+            const uint32_t four[4] = {codes.w[r].x, codes.w[r].y, codes.w[r].z, codes.w[r].w};
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                if (8 * at + e < cnt) {
+                    const double c = (double)((four[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+                    const int b_lo = (int)((c - 0.001) * code_to_bin), b_hi = (int)((c + 1.001) * code_to_bin);
+                    if (b_lo != b_hi || b_hi > nb - 1)
+                        again |= 1u << (8 * r + e);
+                    else
+                        count(b_lo);
+                }
+            }
+        }
+        while (again) {
+            const int bit = __builtin_ctz(again);
+            again &= again - 1u;
+            const int k = 8 * ((bit >> 3) * CLOUD_THREADS + threadIdx.x) + (bit & 7);
+            const CloudPoint p = cloud_point(v.g, v.i0 + k, A.dims);
+            count(fx_hist_bin(cloud_projection(p.x, p.y, p.z, st), step, inv_step, nb));
+        }
+        if (packed) {
+            // even and odd fields apart, 16 bits each: a wave's sum of a field stays below 2^16
+            const u64 even = fx_wave_sum_u64(fields & 0x00ff00ff00ff00ffull);
+            const u64 odd = fx_wave_sum_u64((fields >> 8) & 0x00ff00ff00ff00ffull);
+            if (fx_lane() < nb) {
+                const int b = fx_lane();   // (lanes 0-7: word b of copy (lane mod 4) of their wave)
+                mine[b] = (uint32_t)(((b & 1) ? odd : even) >> (16 * (b >> 1))) & 0xffffu;
+            }
+        }
     }
     __syncthreads();
-    if (threadIdx.x < HIST_MAX)
-        Wk.hpart[(int64_t)chunk * HIST_MAX + threadIdx.x] = hist[threadIdx.x];
+    if (threadIdx.x < nb) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int w = 0; w < CLOUD_WAVES * CLOUD_HIST_COPIES; w++)
+            c += hist[w][threadIdx.x];
+        if (c)
+            atomicAdd(&Wk.ctl[v.cloud].hist[threadIdx.x], (u64)c);
+    }
+    __syncthreads();
 }
 
-// One block per cloud: add the chunk histograms (wave w takes chunks w, w + 4,
-// ..., lane = bin), normalise, write.  Integer sums, so the order is free.
-__device__ __forceinline__ void cloud_finish_body(const PcaArgs &A, const CloudWork &Wk, const int cloud, double *tops,
-                                                  u64 (*cnts)[HIST_MAX])
+// the row's histogram part from the cloud's counts; `top`: the cloud's largest |projection|
+__device__ __forceinline__ void cloud_write_hist(const PcaArgs &A, const CloudCtl *ctl, int64_t set, int64_t n, double top)
 {
-    const int lane = fx_lane(), wave = fx_wave();
-    const int first = Wk.cloud_first[cloud], nch = Wk.cloud_first[cloud + 1] - first;
-    const int64_t set = Wk.cloud_ids[cloud];
-    const int64_t n = A.offsets ? A.offsets[set + 1] - A.offsets[set] : A.N;
-    double top = 0.0;
-    for (int i = threadIdx.x; i < nch; i += FX_BLOCK)
-        top = fmax(top, Wk.part[(int64_t)(first + i) * PART + 10]);
-    top = fx_wave_max_f64(top);
-    u64 cnt = 0;
-    for (int i = wave; i < nch; i += FX_WAVES_PER_BLOCK)
-        cnt += Wk.hpart[(int64_t)(first + i) * HIST_MAX + lane];
-    cnts[wave][lane] = cnt;
-    if (lane == 0)
-        tops[wave] = top;
-    __syncthreads();
     const int nb = A.n_bins;
-    if (wave != 0 || lane >= nb)
+    if ((int)threadIdx.x >= nb)
         return;
-    top = fmax(fmax(tops[0], tops[1]), fmax(tops[2], tops[3]));
     float *out = A.out + set * (9 + nb) + 9;
     if (!(top > 0.0)) {
-        out[lane] = lane == 0 ? 1.0f : 0.0f;
+        out[threadIdx.x] = threadIdx.x == 0 ? 1.0f : 0.0f;
         return;
     }
-    cnt = cnts[0][lane] + cnts[1][lane] + cnts[2][lane] + cnts[3][lane];
-    out[lane] = (float)((double)cnt / (double)n);
+    out[threadIdx.x] = (float)((double)ctl->hist[threadIdx.x] / (double)n);
 }
 
-// The launches of the chain: a block per chunk (or per cloud), or, when the lists were built on the device and
-// their lengths are not known to the host, a fixed grid whose blocks walk the list.
-__device__ __forceinline__ int cloud_list_length(const int32_t *dev_count)
+// ---- the launches: a fixed grid whose blocks walk the chunk (or cloud) list.  `back`: from the last chunk to
+// the first.
+template <typename T>
+__global__ __launch_bounds__(CLOUD_THREADS, 4) void cloud_sum_kernel(PcaArgs A, CloudWork Wk)
 {
-    return dev_count ? *dev_count : (int)gridDim.x;
-}
-
-__global__ __launch_bounds__(CLOUD_THREADS) void cloud_sum_kernel(PcaArgs A, CloudWork Wk)
-{
-    __shared__ double red[CLOUD_WAVES];
-    const int n = cloud_list_length(Wk.n_chunks_dev);
+    __shared__ double red[15 * CLOUD_WAVES];
+    const int n = *Wk.n_chunks_dev;
     for (int chunk = blockIdx.x; chunk < n; chunk += gridDim.x)
-        cloud_sum_body(A, Wk, chunk, red);
+        cloud_sum_step(A, Wk, chunk_view<T>(A, Wk, chunk), chunk, red);
 }
 
-__global__ __launch_bounds__(CLOUD_THREADS) void cloud_rmax_kernel(PcaArgs A, CloudWork Wk)
+// stage 0: after the sums; stage 1 (normalize only): after the distances
+template <typename T>
+__global__ __launch_bounds__(CLOUD_THREADS) void cloud_state_kernel(PcaArgs A, CloudWork Wk, int stage)
 {
-    __shared__ double red[CLOUD_WAVES];
-    const int n = cloud_list_length(Wk.n_chunks_dev);
-    for (int chunk = blockIdx.x; chunk < n; chunk += gridDim.x)
-        cloud_rmax_body(A, Wk, chunk, red);
-}
-
-__global__ __launch_bounds__(CLOUD_THREADS) void cloud_proj_kernel(PcaArgs A, CloudWork Wk)
-{
-    __shared__ double red[CLOUD_WAVES];
-    const int n = cloud_list_length(Wk.n_chunks_dev);
-    for (int chunk = blockIdx.x; chunk < n; chunk += gridDim.x)
-        cloud_proj_body(A, Wk, chunk, red);
-}
-
-__global__ __launch_bounds__(CLOUD_THREADS) void cloud_hist_kernel(PcaArgs A, CloudWork Wk)
-{
-    __shared__ double red[CLOUD_WAVES];
-    __shared__ uint32_t hist[HIST_MAX];
-    const int n = cloud_list_length(Wk.n_chunks_dev);
-    for (int chunk = blockIdx.x; chunk < n; chunk += gridDim.x) {
-        cloud_hist_body(A, Wk, chunk, red, hist);
-        __syncthreads();  // the histogram has been written out before the next chunk clears it
+    __shared__ double red[15 * CLOUD_WAVES];
+    const int n = *Wk.n_clouds_dev;
+    for (int cloud = blockIdx.x; cloud < n; cloud += gridDim.x) {
+        const ChunkView<T> v = cloud_view<T>(A, Wk, cloud);
+        if (v.nch > 0)
+            cloud_state_step(A, Wk, v, stage == 1, red);
+        __syncthreads();
     }
 }
 
-__global__ __launch_bounds__(FX_BLOCK) void cloud_finish_kernel(PcaArgs A, CloudWork Wk)
+template <typename T>
+__global__ __launch_bounds__(CLOUD_THREADS, 4) void cloud_rmax_kernel(PcaArgs A, CloudWork Wk, int back)
 {
-    __shared__ double tops[FX_WAVES_PER_BLOCK];
-    __shared__ u64 cnts[FX_WAVES_PER_BLOCK][HIST_MAX];
-    const int n = cloud_list_length(Wk.n_clouds_dev);
+    __shared__ double red[CLOUD_WAVES];
+    const int n = *Wk.n_chunks_dev;
+    for (int k = blockIdx.x; k < n; k += gridDim.x) {
+        const int chunk = back ? n - 1 - k : k;
+        cloud_rmax_step(A, Wk, chunk_view<T>(A, Wk, chunk), red);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(CLOUD_THREADS, 4) void cloud_proj_kernel(PcaArgs A, CloudWork Wk, int back)
+{
+    __shared__ double red[CLOUD_WAVES];
+    __shared__ __align__(16) uint16_t stage[CLOUD_CHUNK];
+    const int n = *Wk.n_chunks_dev;
+    for (int k = blockIdx.x; k < n; k += gridDim.x) {
+        const int chunk = back ? n - 1 - k : k;
+        const ChunkView<T> v = chunk_view<T>(A, Wk, chunk);
+        double st[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            st[q] = Wk.state[(int64_t)v.cloud * STATE + q];
+        cloud_proj_step(A, Wk, v, chunk, st, stage, red);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(CLOUD_THREADS, 4) void cloud_hist_kernel(PcaArgs A, CloudWork Wk, int back)
+{
+    __shared__ uint32_t hist[CLOUD_WAVES * CLOUD_HIST_COPIES][CLOUD_HIST_PITCH];
+    const int n = *Wk.n_chunks_dev;
+    for (int k = blockIdx.x; k < n; k += gridDim.x) {
+        const int chunk = back ? n - 1 - k : k;
+        const CloudCodes codes = cloud_load_codes(Wk, chunk);   // (on their way while the chunk is looked up)
+        const ChunkView<T> v = chunk_view<T>(A, Wk, chunk);
+        double st[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            st[q] = Wk.state[(int64_t)v.cloud * STATE + q];
+        const double top = __longlong_as_double((long long)Wk.ctl[v.cloud].top_bits);
+        cloud_hist_step(A, Wk, v, codes, st, top, hist);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(CLOUD_THREADS) void cloud_finish_kernel(PcaArgs A, CloudWork Wk)
+{
+    const int n = *Wk.n_clouds_dev;
     for (int cloud = blockIdx.x; cloud < n; cloud += gridDim.x) {
-        cloud_finish_body(A, Wk, cloud, tops, cnts);
-        __syncthreads();
+        const ChunkView<T> v = cloud_view<T>(A, Wk, cloud);
+        if (v.nch > 0)   // block-uniform
+            cloud_write_hist(A, Wk.ctl + cloud, v.set, v.n, __longlong_as_double((long long)Wk.ctl[cloud].top_bits));
     }
 }
 
@@ -1674,7 +1901,8 @@ int launch_full_sets(const PcaArgs &A, hipStream_t s)
     FX_REQUIRE(blocks <= 0x7fffffffLL, "fx_pca_batch_f32: too many sets for one launch");
     const int64_t n = (int64_t)FX_WAVE * PPL;
     FX_REQUIRE(A.redo_list && A.redo_count, "fx_pca_batch_f32: no list for the sets to redo");
-    FX_HIP_CHECK(hipMemsetAsync(A.redo_count, 0, sizeof(int32_t), s));
+    if (!A.redo_zeroed)
+        FX_HIP_CHECK(hipMemsetAsync(A.redo_count, 0, sizeof(int32_t), s));
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(FX_WAVE * NW), 0, s, A, 1.0 / (double)n, 1.0 / (double)(n - 1),
                        1.0 / (double)A.n_bins);
     PcaArgs R = A;
@@ -1695,7 +1923,8 @@ int launch_ragged_sets(const PcaArgs &A, hipStream_t s)
     const int64_t blocks = (A.n_sets + NW - 1) / NW;
     FX_REQUIRE(blocks <= 0x7fffffffLL, "fx_pca_batch_f32: too many sets for one launch");
     FX_REQUIRE(A.redo_list && A.redo_count, "fx_pca_batch_f32: no list for the sets to redo");
-    FX_HIP_CHECK(hipMemsetAsync(A.redo_count, 0, sizeof(int32_t), s));
+    if (!A.redo_zeroed)
+        FX_HIP_CHECK(hipMemsetAsync(A.redo_count, 0, sizeof(int32_t), s));
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(FX_WAVE * NW), 0, s, A, 0.0, 0.0, 1.0 / (double)A.n_bins);
     PcaArgs R = A;
     R.set_ids = A.redo_list;
@@ -1713,7 +1942,8 @@ int launch_quad_sets(const PcaArgs &A, hipStream_t s)
     const int64_t blocks = (waves + NW - 1) / NW;
     FX_REQUIRE(blocks <= 0x7fffffffLL, "fx_pca_batch_f32: too many sets for one launch");
     FX_REQUIRE(A.redo_list && A.redo_count, "fx_pca_batch_f32: no list for the sets to redo");
-    FX_HIP_CHECK(hipMemsetAsync(A.redo_count, 0, sizeof(int32_t), s));
+    if (!A.redo_zeroed)
+        FX_HIP_CHECK(hipMemsetAsync(A.redo_count, 0, sizeof(int32_t), s));
     hipLaunchKernelGGL((pca_sets_quad_kernel<NW>), dim3((unsigned)blocks), dim3(FX_WAVE * NW), 0, s, A, 1.0 / (double)A.n_bins);
     PcaArgs R = A;
     R.set_ids = A.redo_list;
@@ -1754,19 +1984,31 @@ int launch_small_sets(const PcaArgs &A, int64_t max_points, hipStream_t s)
 // (with their chunk lists).  The list lengths stay in device memory; the
 // launches that consume them are sized by upper bounds and their surplus blocks
 // leave at once (set kernels) or their blocks walk the list (cloud chain).
+// Work lists of a batch: the sets of a CSR batch sorted by the kernel that takes them (built on the device by
+// pca_classify_kernel), and for the large clouds the chunk lists.
 struct RaggedLists {
-    int32_t *counts;       // [0] register sets, [1] sets of 1025..2048 points, [2] large clouds, [3] chunks, [4] small sets
+    int32_t *counts;       // [0] register-path sets, [1] LDS-path sets, [2] large clouds, [3] chunks, [4] small sets;
+                           // [16] - [18] sets that the three set launches leave to their second kernel
     int32_t *reg_ids;      // [B]
     int32_t *lds_ids;      // [B]
     int32_t *quad_ids;     // [B] sets of up to QUAD_MAX_POINTS points (four per wave)
     int32_t *cloud_ids;    // [max_clouds]
     int32_t *cloud_first;  // [max_clouds + 1]
-    int32_t *chunk_cloud;  // [max_chunks]
+    CloudChunk *chunks;    // [max_chunks]
+    CloudCtl *ctl;         // [max_clouds]
     int64_t max_clouds, max_chunks;
+    int64_t total;         // points behind the caller's pointer (CSR batches), or 0
 };
 
+__device__ __forceinline__ int64_t pca_set_size(const PcaArgs &A, int64_t set)
+{
+    return A.offsets ? A.offsets[set + 1] - A.offsets[set] : A.N;
+}
+
 constexpr int CLASSIFY_THREADS = 1024, CLASSIFY_WAVES = CLASSIFY_THREADS / FX_WAVE;
-__global__ __launch_bounds__(CLASSIFY_THREADS) void pca_classify_kernel(PcaArgs A, RaggedLists L, int64_t B, int64_t reg_max)
+// all_clouds: every set goes to the cloud list (float64 input)
+__global__ __launch_bounds__(CLASSIFY_THREADS) void pca_classify_kernel(PcaArgs A, RaggedLists L, int64_t B, int64_t reg_max,
+                                                                       int all_clouds)
 {
     // one atomic per block and list (thousands of waves adding to the same four counters take turns at the L2);
     // within a block the sets keep their order
@@ -1774,10 +2016,14 @@ __global__ __launch_bounds__(CLASSIFY_THREADS) void pca_classify_kernel(PcaArgs 
     __shared__ int block_base[4];
     const int64_t b = (int64_t)blockIdx.x * CLASSIFY_THREADS + threadIdx.x;
     int cls = -1;
+    bool bad = false;
     if (b < B) {
-        // a set of fewer than three points (or with decreasing offsets) gets its NaN row from the set kernels
-        const int64_t n = A.offsets[b + 1] - A.offsets[b];
-        cls = n <= QUAD_MAX_POINTS ? 3 : n <= reg_max ? 0 : n <= WAVE_SET_MAX_POINTS ? 1 : 2;
+        // a set of fewer than three points (or with decreasing offsets) gets its NaN row from the set kernels;
+        // one that reaches beyond the caller's point count gets it here: nothing behind that count is read
+        const int64_t n = pca_set_size(A, b);
+        bad = A.offsets && L.total > 0 && (A.offsets[b] < 0 || A.offsets[b + 1] > L.total);
+        if (!bad)
+            cls = all_clouds ? 2 : n <= QUAD_MAX_POINTS ? 3 : n <= reg_max ? 0 : n <= WAVE_SET_MAX_POINTS ? 1 : 2;
     }
     const int lane = fx_lane(), wave = fx_wave();
     unsigned long long mine = 0ull;   // the lanes of this wave in the same list as this lane
@@ -1805,67 +2051,163 @@ __global__ __launch_bounds__(CLASSIFY_THREADS) void pca_classify_kernel(PcaArgs 
         int32_t *list = cls == 0 ? L.reg_ids : cls == 1 ? L.lds_ids : cls == 2 ? L.cloud_ids : L.quad_ids;
         if (cls != 2 || pos < L.max_clouds)
             list[pos] = (int32_t)b;
+        else
+            bad = true;   // more large clouds than the point count allows: the offsets overlap
     }
+    if (bad)
+        write_nan_row(A, b, 0, 1);
 }
 
-// One block: exclusive prefix of the clouds' chunk counts -> cloud_first, total -> counts[3].
+// One block.  Exclusive prefix of the clouds' chunk counts -> cloud_first, total -> counts[3]; clouds of fewer
+// than three points, and clouds behind the point at which the chunk list would overflow (offsets that overlap),
+// get no chunks (pca_chunk_fill_kernel writes their NaN rows).
 __global__ __launch_bounds__(1024) void pca_cloud_scan_kernel(PcaArgs A, RaggedLists L)
 {
-    __shared__ int wave_tot[16];
-    __shared__ int carry_s;
+    __shared__ long long wave_tot[16];
+    __shared__ int carry_s, valid_s;
     const int t = threadIdx.x, lane = fx_lane(), wave = fx_wave();
     int n_clouds = L.counts[2];
     n_clouds = n_clouds < L.max_clouds ? n_clouds : (int)L.max_clouds;
     if (t == 0)
-        carry_s = 0;
+        carry_s = 0, valid_s = 0;
     __syncthreads();
     for (int i0 = 0; i0 < n_clouds; i0 += 1024) {
         const int i = i0 + t;
         int nch = 0;
         if (i < n_clouds) {
-            const int64_t set = L.cloud_ids[i];
-            const int64_t n = A.offsets[set + 1] - A.offsets[set];
-            nch = (int)((n + CLOUD_CHUNK - 1) / CLOUD_CHUNK);
+            const int64_t n = pca_set_size(A, L.cloud_ids[i]);
+            const int64_t c = n < 3 ? 0 : (n + CLOUD_CHUNK - 1) / CLOUD_CHUNK;
+            nch = c > L.max_chunks ? (int)L.max_chunks + 1 : (int)c;
         }
-        int inc = nch;
+        long long inc = nch;
 #pragma unroll
         for (int o = 1; o < FX_WAVE; o <<= 1) {
-            const int u = __shfl_up(inc, o, FX_WAVE);
+            const long long u = __shfl_up(inc, o, FX_WAVE);
             if (lane >= o)
                 inc += u;
         }
         if (lane == FX_WAVE - 1)
             wave_tot[wave] = inc;
         __syncthreads();
-        int before = carry_s;
+        long long before = carry_s;
         for (int w = 0; w < wave; w++)
             before += wave_tot[w];
-        if (i < n_clouds)
-            L.cloud_first[i] = before + inc - nch;
+        if (i < n_clouds) {
+            const bool fits = before + inc <= L.max_chunks;
+            L.cloud_first[i] = fits ? (int)(before + inc - nch) : -1;
+            if (fits)
+                atomicMax(&valid_s, (int)(before + inc));
+        }
         __syncthreads();
-        if (t == 1023)
-            carry_s = before + inc;
+        if (t == 1023) {
+            const long long c = before + inc;
+            carry_s = c > L.max_chunks ? (int)L.max_chunks + 1 : (int)c;   // (stays beyond the limit once it is)
+        }
         __syncthreads();
     }
+    const int total = valid_s;
+    for (int i = t; i < n_clouds; i += 1024)
+        if (L.cloud_first[i] < 0)
+            L.cloud_first[i] = total;
     if (t == 0) {
-        L.cloud_first[n_clouds] = carry_s;
-        L.counts[3] = carry_s < L.max_chunks ? carry_s : (int)L.max_chunks;
+        L.cloud_first[n_clouds] = total;
+        L.counts[3] = total;
         L.counts[2] = n_clouds;
     }
 }
 
-__global__ __launch_bounds__(FX_BLOCK) void pca_chunk_fill_kernel(RaggedLists L)
+// A wave per cloud: its chunks' descriptors, its control record cleared; a cloud without chunks gets
+// its NaN row here.
+__global__ __launch_bounds__(FX_BLOCK) void pca_chunk_fill_kernel(PcaArgs A, RaggedLists L)
 {
     const int n_clouds = L.counts[2];
-    for (int i = blockIdx.x * FX_BLOCK + threadIdx.x; i < n_clouds; i += gridDim.x * FX_BLOCK) {
+    const int lane = fx_lane();
+    for (int i = blockIdx.x * FX_WAVES_PER_BLOCK + fx_wave(); i < n_clouds; i += gridDim.x * FX_WAVES_PER_BLOCK) {
         const int a = L.cloud_first[i], b = L.cloud_first[i + 1];
-        for (int c = a; c < b && c < L.max_chunks; c++)
-            L.chunk_cloud[c] = i;
+        if (a == b) {
+            write_nan_row(A, L.cloud_ids[i], lane, FX_WAVE);
+            continue;
+        }
+        const int64_t set = L.cloud_ids[i];
+        const int64_t n = pca_set_size(A, set);
+        CloudChunk d;
+        d.base = A.offsets ? A.offsets[set] : set * A.N;
+        d.cloud = i;
+        d.pad[0] = d.pad[1] = 0;
+        for (int c = a + lane; c < b; c += FX_WAVE) {
+            d.i0 = (int64_t)(c - a) * CLOUD_CHUNK;
+            d.count = (int32_t)(n - d.i0 < CLOUD_CHUNK ? n - d.i0 : CLOUD_CHUNK);
+            L.chunks[c] = d;
+        }
+        u64 *z = reinterpret_cast<u64 *>(L.ctl + i);
+        for (int k = lane; k < (int)(sizeof(CloudCtl) / sizeof(u64)); k += FX_WAVE)
+            z[k] = 0ull;
     }
 }
 
-// Builds the chunk lists for the given large clouds (set index + point count,
-// host arrays) and runs the passes.
+__global__ __launch_bounds__(FX_BLOCK) void pca_iota_kernel(int32_t *ids, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * FX_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * FX_BLOCK)
+        ids[i] = (int32_t)i;
+}
+
+// Scratch of the cloud path: lists, queue, records behind `base` (NULL: only the size is wanted).  Returns the
+// bytes used.
+size_t cloud_layout(unsigned char *base, int64_t max_clouds, int64_t max_chunks, RaggedLists &L, CloudWork &Wk)
+{
+    size_t at = 0;
+    auto take = [&](size_t bytes) {
+        unsigned char *p = base ? base + at : nullptr;
+        at += (bytes + 255) & ~(size_t)255;
+        return p;
+    };
+    L.cloud_ids = (int32_t *)take((size_t)(max_clouds + 1) * sizeof(int32_t));
+    L.cloud_first = (int32_t *)take((size_t)(max_clouds + 1) * sizeof(int32_t));
+    L.chunks = (CloudChunk *)take((size_t)max_chunks * sizeof(CloudChunk));
+    L.ctl = (CloudCtl *)take((size_t)max_clouds * sizeof(CloudCtl));
+    Wk.part = (double *)take((size_t)max_chunks * PART * sizeof(double));
+    Wk.state = (double *)take((size_t)max_clouds * STATE * sizeof(double));
+    Wk.codes = (uint16_t *)take((size_t)max_chunks * CLOUD_CHUNK * sizeof(uint16_t));
+    L.max_clouds = max_clouds;
+    L.max_chunks = max_chunks;
+    Wk.cloud_ids = L.cloud_ids;
+    Wk.cloud_first = L.cloud_first;
+    Wk.chunks = L.chunks;
+    Wk.ctl = L.ctl;
+    Wk.n_clouds_dev = L.counts + 2;
+    Wk.n_chunks_dev = L.counts + 3;
+    return at;
+}
+
+// Enqueues everything behind the cloud list: L.cloud_ids[0 .. counts[2]) hold the clouds (device memory).
+template <typename T>
+int run_clouds(const PcaArgs &A, RaggedLists &L, CloudWork &Wk, hipStream_t s)
+{
+    const int64_t max_clouds = L.max_clouds, max_chunks = L.max_chunks;
+    if (max_clouds == 0 || max_chunks == 0)
+        return FX_OK;
+    hipLaunchKernelGGL(pca_cloud_scan_kernel, dim3(1), dim3(1024), 0, s, A, L);
+    hipLaunchKernelGGL(pca_chunk_fill_kernel, dim3((unsigned)(max_clouds < 4096 ? (max_clouds + FX_WAVES_PER_BLOCK - 1) / FX_WAVES_PER_BLOCK : 1024)),
+                       dim3(FX_BLOCK), 0, s, A, L);
+    const dim3 cgrid((unsigned)(max_chunks < 4096 ? max_chunks : 4096)), block(CLOUD_THREADS);
+    const dim3 sgrid((unsigned)(max_clouds < 1024 ? max_clouds : 1024));
+    int back = 1;   // (the passes over the points alternate in direction)
+    hipLaunchKernelGGL(cloud_sum_kernel<T>, cgrid, block, 0, s, A, Wk);
+    hipLaunchKernelGGL(cloud_state_kernel<T>, sgrid, block, 0, s, A, Wk, 0);
+    if (A.normalize) {
+        hipLaunchKernelGGL(cloud_rmax_kernel<T>, cgrid, block, 0, s, A, Wk, back);
+        hipLaunchKernelGGL(cloud_state_kernel<T>, sgrid, block, 0, s, A, Wk, 1);
+        back ^= 1;
+    }
+    hipLaunchKernelGGL(cloud_proj_kernel<T>, cgrid, block, 0, s, A, Wk, back);
+    hipLaunchKernelGGL(cloud_hist_kernel<T>, cgrid, block, 0, s, A, Wk, back);   // (the codes of the chunks just projected first)
+    hipLaunchKernelGGL(cloud_finish_kernel<T>, sgrid, block, 0, s, A, Wk);
+    FX_HIP_CHECK(hipGetLastError());
+    return FX_OK;
+}
+
+// The cloud path for clouds the host knows (set index + point count, host arrays).
+template <typename T>
 int launch_large_clouds(const PcaArgs &A, const int32_t *h_sets, const int64_t *h_sizes, int64_t n_clouds,
                         FxCallGuard &guard)
 {
@@ -1873,87 +2215,55 @@ int launch_large_clouds(const PcaArgs &A, const int32_t *h_sets, const int64_t *
     int64_t n_chunks = 0;
     for (int64_t k = 0; k < n_clouds; k++)
         n_chunks += (h_sizes[k] + CLOUD_CHUNK - 1) / CLOUD_CHUNK;
-    FX_REQUIRE(n_chunks <= 0x7fffffffLL && n_clouds <= 0x7fffffffLL, "fx_pca_batch_f32: too many chunks for one launch");
-    const size_t ints = (size_t)n_clouds + (size_t)(n_clouds + 1) + (size_t)n_chunks;
-    int32_t *h = (int32_t *)malloc(ints * sizeof(int32_t));
-    if (!h) {
-        fx_set_error("fx_pca_batch_f32: host allocation failed");
+    FX_REQUIRE(n_chunks <= 0x1fffffffLL && n_clouds <= 0x7fffffffLL, "fx_pca_batch_f32: too many chunks for one launch");
+    RaggedLists L = {};
+    CloudWork Wk = {};
+    const size_t counts_bytes = 256;
+    L.counts = nullptr;
+    const size_t need = counts_bytes + cloud_layout(nullptr, n_clouds, n_chunks, L, Wk);
+    unsigned char *base = (unsigned char *)guard.scratch(need, 2);
+    if (!base)
         return FX_ENOMEM;
-    }
-    int32_t *h_ids = h, *h_first = h + n_clouds, *h_cc = h_first + n_clouds + 1;
-    int64_t c = 0;
-    for (int64_t k = 0; k < n_clouds; k++) {
-        h_ids[k] = h_sets[k];
-        h_first[k] = (int32_t)c;
-        const int64_t nch = (h_sizes[k] + CLOUD_CHUNK - 1) / CLOUD_CHUNK;
-        for (int64_t j = 0; j < nch; j++)
-            h_cc[c++] = (int32_t)k;
-    }
-    h_first[n_clouds] = (int32_t)c;
-
-    const size_t list_bytes = (ints * sizeof(int32_t) + 15) & ~(size_t)15;
-    const size_t part_bytes = (size_t)n_chunks * PART * sizeof(double);
-    const size_t hist_bytes = (size_t)n_chunks * HIST_MAX * sizeof(uint32_t);
-    const size_t state_bytes = (size_t)n_clouds * STATE * sizeof(double);
-    unsigned char *base = (unsigned char *)guard.scratch(list_bytes + part_bytes + hist_bytes + state_bytes, 2);
-    if (!base) {
-        free(h);
-        return FX_ENOMEM;
-    }
-    hipError_t e = hipMemcpyAsync(base, h, ints * sizeof(int32_t), hipMemcpyHostToDevice, s);
+    L.counts = (int32_t *)base;
+    cloud_layout(base + counts_bytes, n_clouds, n_chunks, L, Wk);
+    L.total = 0;
+    FX_HIP_CHECK(hipMemsetAsync(L.counts, 0, counts_bytes, s));
+    const int32_t nc = (int32_t)n_clouds;
+    hipError_t e = hipMemcpyAsync(L.cloud_ids, h_sets, (size_t)n_clouds * sizeof(int32_t), hipMemcpyHostToDevice, s);
     if (e == hipSuccess)
-        e = hipStreamSynchronize(s);  // the pageable host list is freed right below
-    free(h);
+        e = hipMemcpyAsync(L.counts + 2, &nc, sizeof(nc), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(s);  // the host lists are the caller's (pageable) arrays
     if (e != hipSuccess) {
-        fx_set_error("fx_pca_batch_f32: uploading the chunk list failed: %s", hipGetErrorString(e));
+        fx_set_error("fx_pca_batch_f32: uploading the cloud list failed: %s", hipGetErrorString(e));
         return FX_EHIP;
     }
-    CloudWork Wk;
-    Wk.cloud_ids = (const int32_t *)base;
-    Wk.cloud_first = Wk.cloud_ids + n_clouds;
-    Wk.chunk_cloud = Wk.cloud_first + n_clouds + 1;
-    Wk.part = (double *)(base + list_bytes);
-    Wk.hpart = (uint32_t *)(base + list_bytes + part_bytes);
-    Wk.state = (double *)(base + list_bytes + part_bytes + hist_bytes);
-    Wk.n_chunks_dev = nullptr;
-    Wk.n_clouds_dev = nullptr;
-
-    const dim3 grid((unsigned)n_chunks), block(CLOUD_THREADS);
-    hipLaunchKernelGGL(cloud_sum_kernel, grid, block, 0, s, A, Wk);
-    if (A.normalize)
-        hipLaunchKernelGGL(cloud_rmax_kernel, grid, block, 0, s, A, Wk);
-    hipLaunchKernelGGL(cloud_proj_kernel, grid, block, 0, s, A, Wk);
-    hipLaunchKernelGGL(cloud_hist_kernel, grid, block, 0, s, A, Wk);
-    hipLaunchKernelGGL(cloud_finish_kernel, dim3((unsigned)n_clouds), dim3(FX_BLOCK), 0, s, A, Wk);
-    FX_HIP_CHECK(hipGetLastError());
-    return FX_OK;
+    return run_clouds<T>(A, L, Wk, s);
 }
 
 // Ragged batch without a host round trip: `total` is the caller's count of points behind d_pts (an upper bound
-// of offsets[B]), from which the sizes of the lists and of the per-chunk records are bounded.
-int launch_ragged_on_device(const PcaArgs &A, int64_t B, int64_t total, FxCallGuard &guard)
+// of offsets[B]), from which the sizes of the lists and of the per-chunk records are bounded.  all_clouds: every
+// set takes the cloud path (float64 input).
+template <typename T>
+int launch_ragged_on_device(const PcaArgs &A, int64_t B, int64_t total, bool all_clouds, FxCallGuard &guard)
 {
     hipStream_t s = guard.stream;
     auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
     // a large cloud has more than WAVE_SET_MAX_POINTS points, so there are at most total / (that + 1) of them,
     // and sum ceil(n / chunk) <= total / chunk + number of clouds
-    int64_t max_clouds = total / (WAVE_SET_MAX_POINTS + 1);
+    int64_t max_clouds = all_clouds ? B : total / (WAVE_SET_MAX_POINTS + 1);
     max_clouds = max_clouds > B ? B : max_clouds;
     const int64_t max_chunks = max_clouds ? total / CLOUD_CHUNK + max_clouds : 0;
-    FX_REQUIRE(max_chunks <= 0x7fffffffLL, "fx_pca_batch_f32: too many chunks for one launch");
+    FX_REQUIRE(max_chunks <= 0x1fffffffLL, "fx_pca_batch: too many chunks for one launch");
     const size_t counts_bytes = 256;
-    const size_t ids_bytes = align((size_t)B * sizeof(int32_t));
-    const size_t cid_bytes = align((size_t)(max_clouds + 1) * sizeof(int32_t));
-    const size_t cc_bytes = align((size_t)max_chunks * sizeof(int32_t));
-    const size_t part_bytes = align((size_t)max_chunks * PART * sizeof(double));
-    const size_t hist_bytes = align((size_t)max_chunks * HIST_MAX * sizeof(uint32_t));
-    const size_t state_bytes = align((size_t)max_clouds * STATE * sizeof(double));
-    const size_t redo_bytes = align(((size_t)B + 64) * sizeof(int32_t));
-    unsigned char *base = (unsigned char *)guard.scratch(
-        counts_bytes + 3 * ids_bytes + redo_bytes + 2 * cid_bytes + cc_bytes + part_bytes + hist_bytes + state_bytes, 2);
+    const size_t ids_bytes = all_clouds ? 0 : align((size_t)B * sizeof(int32_t));
+    const size_t redo_bytes = all_clouds ? 0 : align(((size_t)B + 64) * sizeof(int32_t));
+    RaggedLists L = {};
+    CloudWork Wk = {};
+    const size_t cloud_bytes = cloud_layout(nullptr, max_clouds, max_chunks, L, Wk);
+    unsigned char *base = (unsigned char *)guard.scratch(counts_bytes + 3 * ids_bytes + redo_bytes + cloud_bytes, 2);
     if (!base)
         return FX_ENOMEM;
-    RaggedLists L;
     unsigned char *p = base;
     L.counts = (int32_t *)p, p += counts_bytes;
     L.reg_ids = (int32_t *)p, p += ids_bytes;
@@ -1961,70 +2271,49 @@ int launch_ragged_on_device(const PcaArgs &A, int64_t B, int64_t total, FxCallGu
     L.quad_ids = (int32_t *)p, p += ids_bytes;
     int32_t *redo = (int32_t *)p;
     p += redo_bytes;
-    L.cloud_ids = (int32_t *)p, p += cid_bytes;
-    L.cloud_first = (int32_t *)p, p += cid_bytes;
-    L.chunk_cloud = (int32_t *)p, p += cc_bytes;
-    L.max_clouds = max_clouds;
-    L.max_chunks = max_chunks;
-    CloudWork Wk;
-    Wk.cloud_ids = L.cloud_ids;
-    Wk.cloud_first = L.cloud_first;
-    Wk.chunk_cloud = L.chunk_cloud;
-    Wk.part = (double *)p, p += part_bytes;
-    Wk.hpart = (uint32_t *)p, p += hist_bytes;
-    Wk.state = (double *)p;
-    Wk.n_chunks_dev = L.counts + 3;
-    Wk.n_clouds_dev = L.counts + 2;
+    cloud_layout(p, max_clouds, max_chunks, L, Wk);
+    L.total = A.offsets ? total : 0;
 
     FX_HIP_CHECK(hipMemsetAsync(L.counts, 0, counts_bytes, s));
     const int64_t reg_max = REG_SET_MAX_POINTS;
     hipLaunchKernelGGL(pca_classify_kernel, dim3((unsigned)((B + CLASSIFY_THREADS - 1) / CLASSIFY_THREADS)), dim3(CLASSIFY_THREADS), 0, s, A, L, B,
-                       reg_max);
+                       reg_max, all_clouds ? 1 : 0);
     FX_HIP_CHECK(hipGetLastError());
     FxProfileScope prof(s);
     int rc = FX_OK;
-    {
+    if (!all_clouds) {
         PcaArgs S = A;
         S.set_ids = L.quad_ids;
         S.n_sets = B;                 // sizes the grid; the kernel reads the true count
         S.n_sets_dev = L.counts + 4;
-        S.redo_count = redo;
+        S.redo_count = L.counts + 16;   // (counts are zero; the launches run one after the other and share the list)
+        S.redo_zeroed = 1;
         S.redo_list = redo + 64;
         rc = launch_quad_sets(S, s);
     }
-    if (rc == FX_OK) {
+    if (rc == FX_OK && !all_clouds) {
         PcaArgs S = A;
         S.set_ids = L.reg_ids;
         S.n_sets = B;
         S.n_sets_dev = L.counts + 0;
-        S.redo_count = redo;          // (the launches run one after the other: they share the list)
+        S.redo_count = L.counts + 17;
+        S.redo_zeroed = 1;
         S.redo_list = redo + 64;
         rc = launch_reg_sets(S, REG_SET_MAX_POINTS, true, s);
     }
-    if (rc == FX_OK) {
+    if (rc == FX_OK && !all_clouds) {
         PcaArgs S = A;
         S.set_ids = L.lds_ids;
         S.n_sets = B;
         S.n_sets_dev = L.counts + 1;
-        S.redo_count = redo;
+        S.redo_count = L.counts + 18;
+        S.redo_zeroed = 1;
         S.redo_list = redo + 64;
         rc = launch_small_sets(S, WAVE_SET_MAX_POINTS, s);
     }
-    if (rc != FX_OK || max_clouds == 0)
+    if (rc != FX_OK)
         return rc;
-    hipLaunchKernelGGL(pca_cloud_scan_kernel, dim3(1), dim3(1024), 0, s, A, L);
-    hipLaunchKernelGGL(pca_chunk_fill_kernel, dim3((unsigned)(max_clouds < 65536 ? (max_clouds + FX_BLOCK - 1) / FX_BLOCK : 256)),
-                       dim3(FX_BLOCK), 0, s, L);
-    const dim3 grid((unsigned)(max_chunks < 2048 ? max_chunks : 2048)), block(CLOUD_THREADS);
-    hipLaunchKernelGGL(cloud_sum_kernel, grid, block, 0, s, A, Wk);
-    if (A.normalize)
-        hipLaunchKernelGGL(cloud_rmax_kernel, grid, block, 0, s, A, Wk);
-    hipLaunchKernelGGL(cloud_proj_kernel, grid, block, 0, s, A, Wk);
-    hipLaunchKernelGGL(cloud_hist_kernel, grid, block, 0, s, A, Wk);
-    hipLaunchKernelGGL(cloud_finish_kernel, dim3((unsigned)(max_clouds < 1024 ? max_clouds : 1024)), dim3(FX_BLOCK), 0, s, A,
-                       Wk);
-    FX_HIP_CHECK(hipGetLastError());
-    return FX_OK;
+    return run_clouds<T>(A, L, Wk, s);
 }
 
 }  // namespace
@@ -2045,6 +2334,7 @@ extern "C" int fx_pca_batch_f32(const float *d_pts, const int64_t *d_offsets, in
     hipStream_t s = (hipStream_t)stream;
     PcaArgs A;
     A.pts = d_pts;
+    A.pts64 = nullptr;
     A.offsets = d_offsets;
     A.set_ids = nullptr;
     A.n_sets = B;
@@ -2058,6 +2348,7 @@ extern "C" int fx_pca_batch_f32(const float *d_pts, const int64_t *d_offsets, in
     A.n_sets_dev = nullptr;
     A.redo_list = nullptr;
     A.redo_count = nullptr;
+    A.redo_zeroed = 0;
     FxCallGuard guard(s);
 
     if (!d_offsets) {
@@ -2087,7 +2378,7 @@ extern "C" int fx_pca_batch_f32(const float *d_pts, const int64_t *d_offsets, in
             sets[b] = (int32_t)b;
             sizes[b] = N;
         }
-        const int rc = launch_large_clouds(A, sets, sizes, B, guard);
+        const int rc = launch_large_clouds<float>(A, sets, sizes, B, guard);
         free(sets);
         free(sizes);
         return rc;
@@ -2095,7 +2386,7 @@ extern "C" int fx_pca_batch_f32(const float *d_pts, const int64_t *d_offsets, in
 
     // Ragged batch.  With the caller's point count the work lists are built on the device and nothing waits.
     if (N > 0)
-        return launch_ragged_on_device(A, B, N, guard);
+        return launch_ragged_on_device<float>(A, B, N, false, guard);
     // Without it: read the offsets back once, route small sets to the LDS
     // kernel and large clouds to the streaming kernel.
     int64_t *h_off = (int64_t *)malloc((size_t)(B + 1) * sizeof(int64_t));
@@ -2197,8 +2488,54 @@ extern "C" int fx_pca_batch_f32(const float *d_pts, const int64_t *d_offsets, in
         rc = launch_small_sets(S, max_small, s);
     }
     if (rc == FX_OK && n_large > 0)
-        rc = launch_large_clouds(A, h_ids + n_small, h_large_sizes, n_large, guard);
+        rc = launch_large_clouds<float>(A, h_ids + n_small, h_large_sizes, n_large, guard);
     free(h_ids);
     free(h_large_sizes);
     return rc;
+}
+
+extern "C" int fx_pca_batch_f64(const double *d_pts, const int64_t *d_offsets, int64_t B, int64_t N, int dims,
+                                int n_bins, int normalize, float *d_out, double *d_eig, void *stream)
+{
+    FX_REQUIRE(B >= 0, "fx_pca_batch_f64: B = %lld", (long long)B);
+    if (B == 0)
+        return FX_OK;
+    FX_REQUIRE(d_pts && d_out, "fx_pca_batch_f64: NULL argument");
+    FX_REQUIRE(dims == 2 || dims == 3, "fx_pca_batch_f64: dims %d must be 2 or 3", dims);
+    FX_REQUIRE(n_bins >= 1 && n_bins <= HIST_MAX, "fx_pca_batch_f64: n_bins %d outside 1..%d", n_bins, HIST_MAX);
+    FX_REQUIRE(d_offsets || N >= 0, "fx_pca_batch_f64: N = %lld", (long long)N);
+    FX_REQUIRE((uintptr_t)d_pts % 8 == 0, "fx_pca_batch_f64: d_pts must be 8-byte aligned");
+    FX_REQUIRE(B <= 0x7fffffffLL, "fx_pca_batch_f64: B too large");
+    hipStream_t s = (hipStream_t)stream;
+    PcaArgs A;
+    A.pts = nullptr;
+    A.pts64 = d_pts;
+    A.offsets = d_offsets;
+    A.set_ids = nullptr;
+    A.n_sets = B;
+    A.N = N;
+    A.dims = dims;
+    A.n_bins = n_bins;
+    A.normalize = normalize;
+    A.out = d_out;
+    A.eig = d_eig;
+    A.slab_floats = 0;
+    A.n_sets_dev = nullptr;
+    A.redo_list = nullptr;
+    A.redo_count = nullptr;
+    A.redo_zeroed = 0;
+    FxCallGuard guard(s);
+    int64_t total = d_offsets ? N : B * N;
+    if (d_offsets && N <= 0) {
+        // the last offset bounds the lists
+        hipError_t e = hipMemcpyAsync(&total, d_offsets + B, sizeof(int64_t), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(s);
+        if (e != hipSuccess) {
+            fx_set_error("fx_pca_batch_f64: reading offsets failed: %s", hipGetErrorString(e));
+            return FX_EHIP;
+        }
+        FX_REQUIRE(total >= 0, "fx_pca_batch_f64: offsets end at %lld", (long long)total);
+    }
+    return launch_ragged_on_device<double>(A, B, total, true, guard);
 }

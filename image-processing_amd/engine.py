@@ -247,14 +247,16 @@ def pca_batch(points: torch.Tensor, offsets: Optional[torch.Tensor] = None, n_bi
               normalize: bool = False, *, eig: bool = False) -> dict:
     """PCA descriptors of point sets.
 
-    points: float32 [B, N, D] (equal-size sets) or, with `offsets` (int64 [B+1]
-    point offsets on the device), float32 [total_points, D]; D is 2 or 3.
+    points: float32 or float64 [B, N, D] (equal-size sets) or, with `offsets`
+    (int64 [B+1] point offsets on the device), [total_points, D]; D is 2 or 3.
+    float64 points are evaluated as they are (the chunked path for every set:
+    slower for small sets; meant for coordinates float32 does not hold exactly).
     Returns {"out": f32 [B, 9+n_bins]} and, with eig=True, "eig" f64 [B,6]
     (lambda1..3, v1).  Sets with fewer than 3 points yield NaN rows.
     """
     _require_cuda(points, "points")
-    if points.dtype != torch.float32 or not points.is_contiguous():
-        raise ValueError("points must be contiguous float32")
+    if points.dtype not in (torch.float32, torch.float64) or not points.is_contiguous():
+        raise ValueError("points must be contiguous float32 or float64")
     stream = _enter(points.device)
     if offsets is None:
         if points.dim() != 3:
@@ -273,8 +275,8 @@ def pca_batch(points: torch.Tensor, offsets: Optional[torch.Tensor] = None, n_bi
         res["eig"] = torch.empty((B, 6), dtype=torch.float64, device=points.device)
     if B == 0:
         return res
-    _lib.call("fx_pca_batch_f32", points.data_ptr(), off_ptr, B, N, D, int(n_bins), int(bool(normalize)),
-              res["out"].data_ptr(), _ptr(res.get("eig")), stream)
+    _lib.call("fx_pca_batch_f64" if points.dtype == torch.float64 else "fx_pca_batch_f32", points.data_ptr(), off_ptr,
+              B, N, D, int(n_bins), int(bool(normalize)), res["out"].data_ptr(), _ptr(res.get("eig")), stream)
     return res
 
 

@@ -9,10 +9,11 @@ Differences from the reference that a caller can observe:
   * `compute_pca_features_batch` / `process_files` exist in addition: they put
     many sets through one kernel launch (the reference has only the per-file
     functions and a multiprocessing pool around them);
-  * inputs are evaluated from their float32 values (the reference's
-    load_sample widens float32 files to float64, which is exact, so file inputs
-    behave identically; float64 arrays handed to compute_pca_features directly
-    are rounded to float32 first).
+  * point sets whose values float32 holds exactly (the float32 files the
+    pipeline writes) run through the float32 kernels, which compute what the
+    reference computes after widening; any other input -- float64 files or
+    arrays with values float32 would round -- is evaluated from its float64
+    values by fx_pca_batch_f64, as load_sample / compute_pca_features do.
 """
 from __future__ import annotations
 
@@ -73,15 +74,17 @@ def compute_pca_features_batch(point_sets: Sequence[np.ndarray], n_bins: int = 8
     if not sets:
         empty = np.zeros((0, 9 + n_bins), dtype=np.float32)
         return (empty, np.zeros((0, 6))) if return_eig else empty
+    from . import ingest
     dims = 3 if sets[0].shape[1] >= 3 else 2
     sizes = np.array([p.shape[0] for p in sets], dtype=np.int64)
+    sets = [ingest.as_device_points(p, dims) for p in sets]
+    if any(p.dtype == np.float64 for p in sets):      # one wide set makes the batch wide (exact either way)
+        sets = [p.astype(np.float64, copy=False) for p in sets]
     if np.all(sizes == sizes[0]):
-        from . import ingest
-        d_pts = ingest.stack_to_device([np.ascontiguousarray(p[:, :dims], dtype=np.float32) for p in sets], dev,
-                                       ingest.default_workers())
+        d_pts = ingest.stack_to_device(sets, dev, ingest.default_workers())
         res = engine.pca_batch(d_pts, None, n_bins, normalize, eig=return_eig)
     else:
-        flat = np.concatenate([np.ascontiguousarray(p[:, :dims], dtype=np.float32) for p in sets], axis=0)
+        flat = np.concatenate(sets, axis=0)
         d_pts = torch.from_numpy(flat).to(dev)
         off = np.zeros(len(sets) + 1, dtype=np.int64)
         np.cumsum(sizes, out=off[1:])

@@ -44,15 +44,28 @@ def map_ordered(fn: Callable[[Any], Any], items: Sequence[Any], workers: int) ->
         return list(pool.map(guarded, items))
 
 
+def as_device_points(arr: np.ndarray, dims: int = 3) -> np.ndarray:
+    """The first `dims` columns of a point array in the narrowest type that holds
+    them exactly: float32 if every value survives the round trip (then the
+    float32 kernels compute what the reference computes from the widened
+    values), float64 otherwise."""
+    a = np.asarray(arr)[:, :dims]
+    if a.dtype == np.float32:
+        return np.ascontiguousarray(a)
+    wide = np.ascontiguousarray(a, dtype=np.float64)
+    narrow = wide.astype(np.float32)
+    same = (narrow.astype(np.float64) == wide) | np.isnan(wide)
+    return narrow if bool(same.all()) else wide
+
+
 def read_npy_points(path) -> np.ndarray:
-    """First three columns of an [N, >=3] .npy file as float32 [N, 3];
-    ValueError on any other shape.  float32 files are read without widening
-    (the reference widens to float64 and the descriptor is evaluated from the
-    float32 values either way)."""
+    """First three columns of an [N, >=3] .npy file as [N, 3] float32, or
+    float64 where float32 would round (load_sample, reference :48-56, hands
+    over the float64 values); ValueError on any other shape."""
     arr = np.load(path, allow_pickle=False, mmap_mode=None)
     if arr.ndim != 2 or arr.shape[1] < 3:
         raise ValueError(f"invalid shape {arr.shape} (expected Nx3) for {path}")
-    return np.ascontiguousarray(arr[:, :3], dtype=np.float32)
+    return as_device_points(arr, 3)
 
 
 def _path_array(paths: Sequence[str]):
@@ -75,7 +88,8 @@ def host_buffer(shape, dtype=np.float32):
 def read_points_batch(paths: Sequence[str], rows: int, out: np.ndarray, workers: int):
     """Native batch read of [rows, >=3] float32/float64 .npy files into
     out[i] (float32 [n, rows, 3]).  Returns (status int32 [n], rows_found int64
-    [n]); status 0 = read, anything else = left to the caller."""
+    [n]); status 0 = read, anything else = left to the caller (float64 files
+    whose values float32 would round among them)."""
     from . import _lib
     n = len(paths)
     status = np.zeros(n, dtype=np.int32)

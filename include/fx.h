@@ -111,6 +111,9 @@ int fx_hu_batch_u8(const uint8_t *d_img, int64_t B, int H, int W,
  * number for larger ones; beyond it the call fails with FX_EINVAL.  All calls
  * on one device share the block: calls that overlap in time on one device
  * (different streams or threads) race and must be ordered by the caller.
+ * The block's address on a device is looked up by fx_init(device), else by
+ * the first call on that device; a first call whose stream is being captured
+ * fails with FX_EINVAL instead (run fx_init on the device beforehand).
  */
 #define FX_HU_NOALLOC_MAX_IMAGES 65536
 int fx_hu_batch_u8_noalloc(const uint8_t *d_img, int64_t B, int H, int W,
@@ -154,6 +157,22 @@ int fx_hu_groupstat(const float *d_hulog7, const int64_t *d_group_offsets,
  */
 int fx_pca_batch_f32(const float *d_pts, const int64_t *d_offsets, int64_t B,
                      int64_t N, int dims, int n_bins, int normalize,
+                     float *d_out, double *d_eig, void *stream);
+
+/*
+ * compute_pca_features on float64 coordinates (reference
+ * src/features/extract_3d_pca_features.py:48-56 + :59-145: load_sample hands
+ * over `arr[:, :3].astype(np.float64)` of whatever the file holds, and the
+ * descriptor is computed from those values).  Same arguments and results as
+ * fx_pca_batch_f32 with d_pts float64; for inputs that float32 does not hold
+ * exactly (float64 files, arrays passed to compute_pca_features directly).
+ * Every set takes the chunked path of the large clouds, whatever its size: a
+ * correctness path, an order of magnitude below the float32 set kernels for
+ * small sets.  Ragged batches need N > 0 (the number of points behind d_pts)
+ * or cost one read-back of the last offset.
+ */
+int fx_pca_batch_f64(const double *d_pts, const int64_t *d_offsets, int64_t B, int64_t N,
+                     int dims, int n_bins, int normalize,
                      float *d_out, double *d_eig, void *stream);
 
 /*
@@ -302,12 +321,16 @@ int fx_allgather_features(const void *d_local, int64_t local_rows, int row_float
 #define FX_IO_EDTYPE 4   /* a sample type or layout this reader leaves to NumPy / PIL */
 #define FX_IO_ESHAPE 5   /* not 2-D with at least 3 columns */
 #define FX_IO_EROWS 6    /* readable, but not of the batch's common size (the found size is reported) */
+#define FX_IO_EWIDE 7    /* float64 samples that float32 does not hold exactly: to be evaluated as float64 */
 
 /*
  * Batch form of load_sample, src/features/extract_3d_pca_features.py:48-56
  * (np.load + [:, :3]): reads n .npy files that each hold a [rows, >=3]
  * float32/float64 array and writes the first three columns as float32 into
- * out[i] (n x rows x 3, host memory, e.g. page-locked).  A file that does not
+ * out[i] (n x rows x 3, host memory, e.g. page-locked).  A float64 file is
+ * taken over only when float32 holds all its samples exactly (load_sample
+ * widens to float64 and the reference computes on those values), otherwise it
+ * gets FX_IO_EWIDE and goes through fx_pca_batch_f64.  A file that does not
  * fit gets a status and is left for the caller (np.load handles every other
  * dtype and raises the reference's errors); status[i] / rows_found[i] per file.
  */

@@ -50,6 +50,17 @@ def pca_golden():
 
 
 @pytest.fixture(scope="session")
+def pca_golden_wide():
+    """Reference outputs for float64 inputs that float32 does not hold exactly."""
+    d = np.load(GOLDEN / "pca_golden_wide.npz")
+    cases = []
+    for k in range(int(d["n_cases"])):
+        nb, nz = d[f"meta_{k}"]
+        cases.append({"pts": d[f"pts_{k}"], "out": d[f"out_{k}"], "n_bins": int(nb), "normalize": bool(nz)})
+    return cases
+
+
+@pytest.fixture(scope="session")
 def gpu():
     """torch device of the MI355X; the tests that use it are marked gpu."""
     import torch

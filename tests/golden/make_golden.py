@@ -11,6 +11,10 @@ pca_golden.npz
     far-from-origin clouds).  Keys: pts_<k> float64 [N,3], out_<k> float32,
     meta_<k> = (n_bins, normalize).
 
+pca_golden_wide.npz
+    The same for float64 inputs that float32 does not hold exactly (what
+    load_sample hands over for a float64 file), incl. clouds far from the origin.
+
 hu_panels.npz
     Data cut from the run artefacts the reference committed:
     reports/sample_images/<id>_hu_preview.png are 1120x224 collages written by
@@ -99,6 +103,41 @@ def make_pca(ref: Path) -> None:
         msg = str(e)
     (HERE / "pca_too_few_message.txt").write_text(msg + "\n")
     print(f"pca_golden.npz: {len(cases)} cases; <3 points -> ValueError({msg!r})")
+
+
+def make_pca_wide(ref: Path) -> None:
+    """pca_golden_wide.npz: float64 coordinates that float32 does not hold exactly, as compute_pca_features gets
+    them from load_sample for a float64 file (:48-56), sets small and large, uniform and shifted far from the
+    origin (where rounding the input to float32 would move the eigenvalues by 1e-7 and more)."""
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, str(ref / "src" / "features"))
+    mod = importlib.import_module("extract_3d_pca_features")
+    rng = np.random.default_rng(20261112)
+    cases = []
+
+    def add(pts, n_bins=8, normalize=False):
+        pts = np.asarray(pts, dtype=np.float64)
+        assert not np.array_equal(pts.astype(np.float32).astype(np.float64), pts)
+        cases.append((pts, n_bins, normalize, mod.compute_pca_features(pts, n_bins=n_bins, normalize=normalize)))
+
+    def cloud(n, scales, shift=(0, 0, 0)):
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        return (rng.normal(size=(n, 3)) * np.asarray(scales)) @ q.T + np.asarray(shift)
+
+    for n in (3, 7, 64, 1024, 1024, 2049, 8192, 8193, 30000):
+        add(cloud(n, np.exp(rng.uniform(np.log(0.05), np.log(1.0), size=3))))
+    add(cloud(1024, (0.31, 0.10, 0.078), shift=(12345.678, -2345.6789, 3456.789)))
+    add(cloud(20000, (0.31, 0.10, 0.078), shift=(1e5 + 0.1, -2e5 + 0.3, 5e4 + 0.7)), n_bins=16)
+    add(cloud(5000, (1.0, 0.5, 0.25)), normalize=True)
+    add(cloud(1024, (1e-3, 5e-4, 2e-4), shift=(1.0, 1.0, 1.0)), n_bins=5, normalize=True)
+    out = {}
+    for k, (pts, nb, nz, vec) in enumerate(cases):
+        out[f"pts_{k}"] = pts
+        out[f"out_{k}"] = vec
+        out[f"meta_{k}"] = np.array([nb, int(nz)], dtype=np.int64)
+    out["n_cases"] = np.array(len(cases))
+    np.savez_compressed(HERE / "pca_golden_wide.npz", **out)
+    print(f"pca_golden_wide.npz: {len(cases)} cases")
 
 
 def make_hu(ref: Path) -> None:
@@ -343,8 +382,13 @@ def make_render(ref: Path) -> None:
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default=os.environ.get("FX_REFERENCE", "/root/reference"))
+    ap.add_argument("--only", default="", help="one fixture group, e.g. pca_wide")
     a = ap.parse_args()
+    if a.only:
+        globals()["make_" + a.only](Path(a.reference))
+        sys.exit(0)
     make_pca(Path(a.reference))
+    make_pca_wide(Path(a.reference))
     make_hu(Path(a.reference))
     make_preprocess(Path(a.reference))
     make_fps(Path(a.reference))

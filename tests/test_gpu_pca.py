@@ -25,6 +25,10 @@ def compare_set(got_out, got_eig, ref_out, ref_eig, n, strict_rel=True):
     # are rounding noise themselves (lambda3, r3 of rank-deficient sets)
     l1 = max(float(lam_ref[0]), 1e-300)
     atol = np.array([l1, l1, l1, 1.0, 1.0, 1.0, 0.0, 0.0, l1]) * 1e-9
+    # ratio12 = l1 / (l2 + 1e-12), ratio23 = l2 / (l3 + 1e-12): what the eigenvalue bar (1e-9 l1 absolute) lets the
+    # denominator move shows in the ratio; next to nothing for a full-rank set, everything where l3 is rounding noise
+    atol[6] = abs(float(ref_out[6])) * EIG_RTOL * l1 / (float(lam_ref[1]) + 1e-12)
+    atol[7] = abs(float(ref_out[7])) * EIG_RTOL * l1 / (float(lam_ref[2]) + 1e-12)
     assert np.all(np.abs(got_out[:9].astype(np.float64) - ref_out[:9]) <= OUT_RTOL * np.abs(ref_out[:9]) + atol)
     moved = np.abs(got_out[9:].astype(np.float64) - ref_out[9:].astype(np.float64)) * n
     assert moved.max() <= 2.5, "histogram differs by more than edge ties"
@@ -46,6 +50,47 @@ def test_reference_golden_vectors(gpu, oracle, pca_golden):
         if np.all(pts[:, 2] == pts[0, 2]):
             assert eig[0][2] == 0.0 and ref_eig[2] == 0.0  # a constant coordinate gives an exact zero, as LAPACK does
     assert ties <= 1
+
+
+def test_float64_inputs_are_evaluated_as_float64(gpu, oracle, pca_golden_wide):
+    """load_sample (reference :48-56) hands compute_pca_features the float64 values of whatever the file holds.
+    Inputs that float32 does not hold exactly take fx_pca_batch_f64: outputs of the reference itself
+    (tests/golden/pca_golden_wide.npz) at the bar of the float32-exact inputs, one by one and as one ragged batch;
+    rounding such an input to float32 first would miss that bar by orders of magnitude far from the origin."""
+    import torch
+    mod, eng = pkg("extract_3d_pca_features"), pkg("engine")
+    ties, narrowed_fails = 0, 0
+    for case in pca_golden_wide:
+        pts = case["pts"]
+        out, eig = mod.compute_pca_features_batch([pts], case["n_bins"], case["normalize"], return_eig=True)
+        ref_out, ref_eig = oracle.compute_pca_features(pts, case["n_bins"], case["normalize"], return_eig=True)
+        np.testing.assert_array_equal(ref_out, case["out"])
+        ties += compare_set(out[0], eig[0], case["out"], ref_eig, pts.shape[0])
+        _, eig32 = oracle.compute_pca_features(pts.astype(np.float32).astype(np.float64), case["n_bins"], case["normalize"],
+                                               return_eig=True)
+        narrowed_fails += int(np.abs(eig32[:3] - ref_eig[:3]).max() > EIG_RTOL * ref_eig[0])
+    assert ties <= 2
+    assert narrowed_fails >= 3      # the fixture does tell float64 evaluation from float32 rounding
+    # one ragged float64 batch through the entry point (default settings only)
+    plain = [c for c in pca_golden_wide if c["n_bins"] == 8 and not c["normalize"]]
+    flat = torch.from_numpy(np.concatenate([c["pts"] for c in plain])).to(gpu)
+    off = np.zeros(len(plain) + 1, dtype=np.int64)
+    np.cumsum([len(c["pts"]) for c in plain], out=off[1:])
+    for total_known in (True, False):
+        pts_arg = flat if total_known else torch.cat([flat, torch.zeros((5, 3), dtype=torch.float64, device=gpu)])
+        res = eng.pca_batch(pts_arg, torch.from_numpy(off).to(gpu), 8, False, eig=True)
+        for k, c in enumerate(plain):
+            _, ref_eig = oracle.compute_pca_features(c["pts"], 8, False, return_eig=True)
+            compare_set(res["out"][k].cpu().numpy(), res["eig"][k].cpu().numpy(), c["out"], ref_eig, len(c["pts"]))
+    # a uniform float64 batch, sets of fewer than three points: NaN rows
+    uni = torch.from_numpy(np.stack([c["pts"][:1024] for c in pca_golden_wide if len(c["pts"]) >= 1024])).to(gpu)
+    res = eng.pca_batch(uni, None, 8, False, eig=True)
+    for k in range(uni.shape[0]):
+        h = uni[k].cpu().numpy()
+        ref_out, ref_eig = oracle.compute_pca_features(h, 8, False, return_eig=True)
+        compare_set(res["out"][k].cpu().numpy(), res["eig"][k].cpu().numpy(), ref_out, ref_eig, 1024)
+    tiny = eng.pca_batch(uni[:, :2].contiguous(), None, 8, False)["out"]
+    assert torch.isnan(tiny).all()
 
 
 def test_single_set_signature_and_errors(gpu, oracle):

@@ -294,9 +294,18 @@ def test_read_npy_points(tmp_path):
     ing = pkg("ingest")
     a = np.random.default_rng(0).normal(size=(50, 6))
     np.save(tmp_path / "a.npy", a)
-    got = ing.read_npy_points(tmp_path / "a.npy")
-    assert got.dtype == np.float32 and got.shape == (50, 3) and got.flags.c_contiguous
+    got = ing.read_npy_points(tmp_path / "a.npy")     # values float32 would round: kept as float64, as load_sample does
+    assert got.dtype == np.float64 and got.shape == (50, 3) and got.flags.c_contiguous
+    np.testing.assert_array_equal(got, a[:, :3])
+    np.save(tmp_path / "a32.npy", a.astype(np.float32).astype(np.float64))
+    got = ing.read_npy_points(tmp_path / "a32.npy")   # a widened float32 file: narrowed back, which is exact
+    assert got.dtype == np.float32 and got.flags.c_contiguous
     np.testing.assert_array_equal(got, a[:, :3].astype(np.float32))
+    for dt in (np.float16, np.int32):
+        np.save(tmp_path / "c.npy", (a * 100).astype(dt))
+        got = ing.read_npy_points(tmp_path / "c.npy")
+        assert got.dtype == np.float32
+        np.testing.assert_array_equal(got.astype(np.float64), (a * 100).astype(dt)[:, :3].astype(np.float64))
     np.save(tmp_path / "b.npy", np.zeros((4, 2)))
     with pytest.raises(ValueError, match="invalid shape"):
         ing.read_npy_points(tmp_path / "b.npy")
@@ -312,7 +321,8 @@ def test_native_npy_batch_io(tmp_path):
         p = tmp_path / f"c{i:02d}.npy"
         np.save(p, pts[i])
         paths.append(str(p))
-    np.save(paths[3], pts[3].astype(np.float64))                       # widened file: rounded back
+    np.save(paths[3], pts[3].astype(np.float64))                       # widened file: narrowed back (exact)
+    np.save(paths[11], pts[11].astype(np.float64) + 1e-9)              # float64 values float32 would round: left wide
     np.save(paths[4], np.concatenate([pts[4], pts[4][:, :2]], axis=1))  # five columns: first three
     np.save(paths[5], pts[5][:10])                                      # other row count
     np.save(paths[6], np.asfortranarray(pts[6]))                        # Fortran order
@@ -322,7 +332,7 @@ def test_native_npy_batch_io(tmp_path):
     paths[10] = str(tmp_path / "missing.npy")
     out = np.full((40, 64, 3), np.nan, dtype=np.float32)
     status, found = ing.read_points_batch(paths, 64, out, 4)
-    expect = {5: lib.load() and 6, 6: 4, 7: 4, 8: 5, 9: 3, 10: 1}
+    expect = {5: lib.load() and 6, 6: 4, 7: 4, 8: 5, 9: 3, 10: 1, 11: 7}
     for i in range(40):
         if i in expect:
             assert status[i] == expect[i], (i, status[i])

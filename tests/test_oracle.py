@@ -8,6 +8,15 @@ import pytest
 from conftest import GOLDEN, pkg
 
 
+def test_pca_restatement_equals_reference_outputs_for_float64_inputs(oracle, pca_golden_wide):
+    """The same for inputs float32 does not hold exactly (tests/golden/pca_golden_wide.npz)."""
+    assert len(pca_golden_wide) >= 10
+    for case in pca_golden_wide:
+        assert not np.array_equal(case["pts"].astype(np.float32).astype(np.float64), case["pts"])
+        out = oracle.compute_pca_features(case["pts"], case["n_bins"], case["normalize"])
+        np.testing.assert_array_equal(out, case["out"])
+
+
 def test_pca_restatement_equals_reference_outputs(oracle, pca_golden):
     """tests/golden/pca_golden.npz holds outputs of the reference's
     compute_pca_features; the restatement must reproduce them bit for bit."""

@@ -82,22 +82,25 @@ if __name__ == "__main__":
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 5
         print(f"h2d pinned -> device -> Hu + contour PCA, {B} x {H}x{W}: {dt*1e3:.2f} ms  {B/dt/1e6:.3f} M img/s  {B*H*W/dt/1e9:.1f} GB/s over PCIe", flush=True)
-    elif what == "c5":
+    elif what in ("c5", "c5p", "c5n"):
+        # c5p: the point clouds only; c5n: the same with normalize (the launch chain instead of the persistent launch)
         import numpy as np
-        ms, gbps = time_hu(64, 8192, 8192, False, reps=5)
-        print(f"c5 hu 64 x 8192x8192 (tiled): {ms:.3f} ms  {gbps:.0f} GB/s", flush=True)
+        if what == "c5":
+            ms, gbps = time_hu(64, 8192, 8192, False, reps=5)
+            print(f"c5 hu 64 x 8192x8192 (tiled): {ms:.3f} ms  {gbps:.0f} GB/s", flush=True)
+        kw = {"normalize": True} if what == "c5n" else {}
         rng = np.random.default_rng(5)
         sizes = np.exp(rng.uniform(np.log(1e4), np.log(4e6), 64)).astype(np.int64)
         off = np.zeros(65, dtype=np.int64); np.cumsum(sizes, out=off[1:])
         pts = eng.synth_points(1, int(off[-1]), seed=5, device=dev).reshape(-1, 3).contiguous()
         d_off = torch.from_numpy(off).to(dev)
-        for _ in range(2): eng.pca_batch(pts, d_off)
+        for _ in range(2): eng.pca_batch(pts, d_off, **kw)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(5): eng.pca_batch(pts, d_off)
+        for _ in range(5): eng.pca_batch(pts, d_off, **kw)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 5 * 1e3
-        print(f"c5 pca 64 clouds, {int(off[-1])} points (1e4..4e6 each): {dt:.3f} ms  {off[-1]*12/dt/1e6:.0f} GB/s of input", flush=True)
+        print(f"{what} pca 64 clouds, {int(off[-1])} points (1e4..4e6 each): {dt:.3f} ms  {off[-1]*12/dt/1e6:.0f} GB/s of input", flush=True)
     elif what == "hu1k":
         for (B,H,W,c) in [(7500,1024,1024,False),(7500,1024,1024,True),(30000,512,512,True),(60000,512,256,True)]:
             ms, gbps = time_hu(B,H,W,c)
