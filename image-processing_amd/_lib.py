@@ -60,6 +60,7 @@ SIGNATURES = {
     "fx_synth_points_f32": (c_int, [c_void_p, c_i64, c_i64, c_u64, c_i64, c_void_p]),
     "fx_profile": (c_int, [c_int]),
     "fx_profile_last_ms": (ctypes.c_double, []),
+    "fx_profile_ms_back": (ctypes.c_double, [c_int]),
     "fx_profile_last_units": (ctypes.c_longlong, []),
 }
 

@@ -60,9 +60,13 @@ std::map<std::pair<int, hipStream_t>, std::unique_ptr<StreamState>> g_streams;
 
 bool g_profile = false;
 // two event pairs: a call that runs two launches of its dominant kernel side by side brackets both
-thread_local hipEvent_t g_ev[2][2] = {};
-thread_local bool g_ev_valid[2] = {false, false};
-thread_local int64_t g_prof_units = 0;
+// A ring of timed launches, so that a caller can read a launch's time some calls later (reading it right away
+// makes the host wait for the launch before it enqueues anything else).
+constexpr int kProfRing = 32;
+thread_local hipEvent_t g_ev[kProfRing][2][2] = {};
+thread_local bool g_ev_valid[kProfRing][2] = {};
+thread_local int64_t g_prof_units[kProfRing] = {};
+thread_local int g_prof_at = 0;   // the latest scope's place in the ring
 
 StreamState *stream_state(hipStream_t stream)
 {
@@ -209,19 +213,22 @@ FxProfileScope::FxProfileScope(hipStream_t s, int64_t units, int pair) : stream(
 {
     if (!active)
         return;
-    if (!g_ev[pair][0]) {
-        if (hipEventCreate(&g_ev[pair][0]) != hipSuccess || hipEventCreate(&g_ev[pair][1]) != hipSuccess) {
-            g_ev[pair][0] = nullptr;
+    if (pair == 0)
+        g_prof_at = (g_prof_at + 1) % kProfRing;
+    const int at = g_prof_at;
+    if (!g_ev[at][pair][0]) {
+        if (hipEventCreate(&g_ev[at][pair][0]) != hipSuccess || hipEventCreate(&g_ev[at][pair][1]) != hipSuccess) {
+            g_ev[at][pair][0] = nullptr;
             active = false;
             return;
         }
     }
     if (pair == 0) {
-        g_prof_units = units;
-        g_ev_valid[1] = false;
+        g_prof_units[at] = units;
+        g_ev_valid[at][1] = false;
     }
-    g_ev_valid[pair] = false;
-    if (hipEventRecord(g_ev[pair][0], stream) != hipSuccess)
+    g_ev_valid[at][pair] = false;
+    if (hipEventRecord(g_ev[at][pair][0], stream) != hipSuccess)
         active = false;
 }
 
@@ -229,8 +236,8 @@ FxProfileScope::~FxProfileScope()
 {
     if (!active)
         return;
-    if (hipEventRecord(g_ev[pair][1], stream) == hipSuccess)
-        g_ev_valid[pair] = true;
+    if (hipEventRecord(g_ev[g_prof_at][pair][1], stream) == hipSuccess)
+        g_ev_valid[g_prof_at][pair] = true;
 }
 
 extern "C" {
@@ -314,26 +321,31 @@ int fx_profile(int enable)
     return FX_OK;
 }
 
-long long fx_profile_last_units(void) { return (long long)g_prof_units; }
+long long fx_profile_last_units(void) { return (long long)g_prof_units[g_prof_at]; }
 
-double fx_profile_last_ms(void)
+double fx_profile_ms_back(int back)
 {
-    if (!g_ev_valid[0])
+    if (back < 0 || back >= kProfRing)
+        return -1.0;
+    const int at = ((g_prof_at - back) % kProfRing + kProfRing) % kProfRing;
+    if (!g_ev_valid[at][0])
         return -1.0;
     double sum = 0.0;
     int n = 0;
     for (int pair = 0; pair < 2; pair++) {
-        if (!g_ev_valid[pair])
+        if (!g_ev_valid[at][pair])
             continue;
         float ms = 0.f;
-        if (hipEventSynchronize(g_ev[pair][1]) != hipSuccess ||
-            hipEventElapsedTime(&ms, g_ev[pair][0], g_ev[pair][1]) != hipSuccess)
+        if (hipEventSynchronize(g_ev[at][pair][1]) != hipSuccess ||
+            hipEventElapsedTime(&ms, g_ev[at][pair][0], g_ev[at][pair][1]) != hipSuccess)
             return -1.0;
         sum += (double)ms;
         n++;
     }
     return sum / n;
 }
+
+double fx_profile_last_ms(void) { return fx_profile_ms_back(0); }
 
 }  // extern "C"
 

@@ -483,6 +483,12 @@ def profile_last_ms() -> float:
     return float(_lib.load().fx_profile_last_ms())
 
 
+def profile_ms_back(back: int) -> float:
+    """profile_last_ms of the `back`-th timed call before the most recent one (the library keeps the last 32):
+    read after the following calls have been enqueued, it does not hold the host up."""
+    return float(_lib.load().fx_profile_ms_back(int(back)))
+
+
 def profile_last_units() -> int:
     """Units the launch timed by profile_last_ms processed, when the call split its units over several launches of
     that kernel; 0 when the launch processed all of the call's units."""

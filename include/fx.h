@@ -463,10 +463,14 @@ int fx_synth_points_f32(float *d_pts, int64_t B, int64_t N, uint64_t seed,
  * side by side on two streams) brackets one launch per half and reports the
  * mean of the two durations: fx_profile_last_units is the number of units
  * one such launch processed, 0 when a single launch processed all the
- * call's units.
+ * call's units.  fx_profile_ms_back(k) is the same reading for the k-th
+ * timed call before the most recent one (k = 0: the most recent; the last
+ * 32 are kept, per host thread): a caller that reads a call's time only
+ * after it has enqueued the following calls does not hold the host up.
  */
 int fx_profile(int enable);
 double fx_profile_last_ms(void);
+double fx_profile_ms_back(int back);
 long long fx_profile_last_units(void);
 
 #ifdef __cplusplus

@@ -152,13 +152,13 @@ def test_ragged_batch_and_2d(gpu, oracle):
 
 @pytest.mark.parametrize("normalize", [False, True])
 def test_variable_size_clouds_tail_config(gpu, oracle, normalize):
-    """Clouds with log-uniform sizes from 1e3 to 1.5e6 points in one ragged batch
+    """Clouds with log-uniform sizes from 1e3 to 1.5e6 points and one of 4e6 in one ragged batch
     (the load-imbalance configuration): sets up to 2048 points take the register kernels, larger
-    ones are cut into 16384-point chunks spread over the chip."""
+    ones are cut into 8192-point chunks spread over the chip."""
     import torch
     eng = pkg("engine")
     rng = np.random.default_rng(31)
-    sizes = [int(v) for v in np.exp(rng.uniform(np.log(1e3), np.log(1.5e6), size=12))] + [16384, 16385, 2049, 1_200_000]
+    sizes = [int(v) for v in np.exp(rng.uniform(np.log(1e3), np.log(1.5e6), size=12))] + [16384, 16385, 2049, 8192, 8193, 1_200_000, 4_000_000]
     sets = []
     for n in sizes:
         q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
@@ -183,6 +183,33 @@ def test_variable_size_clouds_tail_config(gpu, oracle, normalize):
     torch.cuda.synchronize()
     np.testing.assert_allclose(out2.cpu().numpy(), out, rtol=1e-6, atol=0)
     np.testing.assert_allclose(eig2.cpu().numpy()[:, :3], eig[:, :3], rtol=1e-12, atol=0)
+
+
+def test_point_count_smaller_than_the_offsets_say(gpu):
+    """The caller's point count bounds what may be read: sets that reach beyond it get NaN rows, whichever
+    kernel their size would have sent them to; the sets inside it are computed as ever."""
+    import torch
+    eng = pkg("engine")
+    rng = np.random.default_rng(77)
+    sizes = [100, 5000, 300, 20000, 3, 1500]
+    off = np.zeros(len(sizes) + 1, dtype=np.int64)
+    np.cumsum(sizes, out=off[1:])
+    flat = torch.from_numpy(rng.normal(size=(int(off[-1]), 3)).astype(np.float32)).to(gpu)
+    d_off = torch.from_numpy(off).to(gpu)
+    full = eng.pca_batch(flat, d_off, 8, False)["out"].cpu().numpy()
+    assert np.isfinite(full).all()
+    out = torch.zeros((len(sizes), 17), dtype=torch.float32, device=gpu)
+    for cut in (int(off[2]) + 10, int(off[3]) + 4096, int(off[1])):
+        out.zero_()
+        pkg("_lib").call("fx_pca_batch_f32", flat.data_ptr(), d_off.data_ptr(), len(sizes), cut, 3, 8, 0,
+                         out.data_ptr(), 0, int(torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        for b in range(len(sizes)):
+            if off[b + 1] <= cut:
+                np.testing.assert_array_equal(got[b], full[b])
+            else:
+                assert np.isnan(got[b]).all(), (cut, b, got[b])
 
 
 def test_full_size_properties(gpu):
