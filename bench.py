@@ -257,9 +257,14 @@ def dry_run(args) -> None:
     want = torch.arange(world, dtype=torch.float32).repeat_interleave(rows)
     assert torch.equal(table[:, 0], want)
     sizes = tail_cloud_sizes()
-    mine = fxdist.lpt_assign([float(s) for s in sizes], world)[rank]
+    assign = fxdist.lpt_assign([float(s) for s in sizes], world)
+    mine = assign[rank]
+    tagged = fxdist.all_gather_tagged_rows(torch.tensor([[float(i), float(sizes[i])] for i in mine]).reshape(len(mine), 2), mine,
+                                           max(len(a) for a in assign), len(sizes))
+    assert torch.equal(tagged[:, 0], torch.arange(len(sizes), dtype=torch.float32))
+    report = fxdist.describe_ranks(1.0 + rank, "cpu")
     if rank == 0:
-        print(json.dumps({"dry_run": True, "n_gpus": world, "rows": int(table.shape[0]), "lpt_units_rank0": len(mine)}), flush=True)
+        print(json.dumps({"dry_run": True, "n_gpus": world, "rows": int(table.shape[0]), "lpt_units_rank0": len(mine), **report}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -323,7 +328,6 @@ def main(argv=None):
         flat = torch.cat(clouds) if clouds else torch.empty((0, 3), dtype=torch.float32, device=dev)
         del clouds
         cloud_off = torch.from_numpy(np.concatenate([[0], np.cumsum(sizes[mine])]).astype(np.int64)).to(dev)
-        cloud_ids = torch.tensor(mine, dtype=torch.float32, device=dev)
         state.update(flat=flat, cloud_off=cloud_off)
         wl = dict(wl)
         wl["cloud_points_total"] = int(sizes.sum())
@@ -374,12 +378,7 @@ def main(argv=None):
                 # one all-gather per feature block: image rows are equal contiguous shards (padded), cloud rows
                 # carry their unit index because the LPT assignment is not contiguous
                 fxdist.all_gather_rows(hu, total)
-                block = torch.zeros((slot, 18), dtype=torch.float32, device=dev)
-                block[:, 0] = -1.0
-                block[: pca.shape[0], 0] = cloud_ids
-                block[: pca.shape[0], 1:] = pca
-                table = torch.empty((world * slot, 18), dtype=torch.float32, device=dev)
-                dist.all_gather_into_tensor(table, block)
+                fxdist.all_gather_tagged_rows(pca, mine, slot, total)
             return hu, pca
         else:
             r = eng.hu_batch(data, thresh=127, on_value=255, contour_bins=8)
@@ -425,10 +424,25 @@ def main(argv=None):
         rvm.render_views_device(flat, cloud_off, 12, 224)
         kernel_ms = [eng.profile_last_ms()]
     eng.profile(False)
+    ranks = fxdist.describe_ranks(elapsed / args.steps * 1e3, torch.cuda.get_device_name(dev))
+    gather_ms = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # the exchange step on its own: one all-gather of a step's feature rows with nothing beside it
+        rows = feats[0] if kind == "tail" else feats
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fence()
+        e0.record()
+        if kind != "tail" and wl["scaling"] == "weak":
+            gather.submit(rows)
+            gather.drain()
+        else:
+            fxdist.all_gather_rows(rows, total)
+        e1.record()
+        torch.cuda.synchronize()
+        gather_ms = float(e0.elapsed_time(e1))
 
     out = None
     if rank == 0:
@@ -458,11 +472,14 @@ def main(argv=None):
                        "bytes_per_unit": wl["bytes_per_unit"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "traffic_source": "profiles/traffic.json (rocprofv3 --pmc, separate run)" if traffic is not None else None,
                          "kernel": {"pca": "pca_sets_full_kernel", "hu": "hu_band_kernel", "hu+cpca": "hu_band_kernel",
                                     "tail": "hu_band_kernel", "sil+hu": "sil_mask_kernel",
                                     "views+hu": "render_views_kernel"}[kind],
                          "kernel_ms": kavg, "units_per_launch": launch_units},
         }
+        out.update(ranks)
+        out["all_gather_ms"] = gather_ms
         if kind == "tail":
             out["config"]["cloud_points_total"] = wl["cloud_points_total"]
             out["config"]["cloud_bytes_rank0"] = wl["cloud_bytes_this_rank"]

@@ -60,6 +60,55 @@ def all_gather_rows(local: torch.Tensor, n_units: int) -> torch.Tensor:
     return table[:n_units]
 
 
+def all_gather_tagged_rows(rows: torch.Tensor, ids: Sequence[int], slot: int, n_units: int) -> torch.Tensor:
+    """Gathers rows of units that are NOT sharded contiguously (clouds handed to
+    the ranks by cost, see lpt_assign): every rank passes its [k_r, F] rows and
+    the unit index of each, `slot` >= every k_r is the padded block height, and
+    every rank gets the [n_units, F] table in unit order.  One all-gather of
+    [slot, F + 1] blocks whose first column carries the unit index (-1 in the
+    padding).  Raises if a unit is missing or arrives twice.  Without an
+    initialised process group the rows are put in order locally."""
+    if n_units >= 1 << 24:
+        raise ValueError("unit indices travel as float32: fewer than 2^24 units")
+    k, F = rows.shape
+    if k != len(ids) or k > slot:
+        raise ValueError(f"{k} rows, {len(ids)} ids, slot of {slot}")
+    block = torch.zeros((slot, F + 1), dtype=rows.dtype, device=rows.device)
+    block[:, 0] = -1.0
+    if k:
+        block[:k, 0] = torch.as_tensor(list(ids), dtype=rows.dtype, device=rows.device)
+        block[:k, 1:] = rows
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        gathered = torch.empty((dist.get_world_size() * slot, F + 1), dtype=rows.dtype, device=rows.device)
+        dist.all_gather_into_tensor(gathered, block)
+    else:
+        gathered = block
+    tag = gathered[:, 0]
+    real = tag >= 0
+    where = tag[real].to(torch.int64)
+    seen = torch.bincount(where, minlength=n_units) if where.numel() else torch.zeros(n_units, dtype=torch.int64, device=rows.device)
+    if seen.numel() != n_units or not bool((seen == 1).all()):
+        raise ValueError("tagged gather: a unit is missing, out of range or present twice")
+    table = torch.empty((n_units, F), dtype=rows.dtype, device=rows.device)
+    table[where] = gathered[real][:, 1:]
+    return table
+
+
+def describe_ranks(step_ms: float, device_name: str) -> dict:
+    """What a reader needs to confirm that a multi-process run was one: the size
+    of the process group as the backend reports it, every rank's device, and the
+    spread of the ranks' own step times."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return {"ranks": 1, "backend": None, "devices": [device_name],
+                "ms_per_step_rank_min": step_ms, "ms_per_step_rank_max": step_ms}
+    world = dist.get_world_size()
+    got: list = [None] * world
+    dist.all_gather_object(got, (dist.get_rank(), float(step_ms), str(device_name)))
+    got.sort()
+    return {"ranks": world, "backend": dist.get_backend(), "devices": [g[2] for g in got],
+            "ms_per_step_rank_min": min(g[1] for g in got), "ms_per_step_rank_max": max(g[1] for g in got)}
+
+
 # --------------------------------------------------------------------------
 # One image spread over the ranks as row bands (images too tall for one GPU's
 # share of a batch): the second, and last, exchange step of the path.

@@ -173,9 +173,27 @@ last = pipe.drain()
 want = torch.cat([torch.full((3, 4), float(40 + r)) for r in range(world)])
 assert torch.equal(last, want) and not pipe.pending, (rank, last)
 assert seen == sorted(seen) and all(v % 10 == 0 for v in seen), seen
+# rows of units handed out by cost (not contiguous): padded, id-tagged blocks, one all-gather, unit order back
+import numpy as np
+costs = np.random.default_rng(8).integers(1, 1000, 13)
+assign = fx.lpt_assign([float(c) for c in costs], world)
+mine = assign[rank]
+rows = torch.tensor([[float(costs[i]), float(i) * 0.5, float(rank)] for i in mine], dtype=torch.float32).reshape(len(mine), 3)
+table = fx.all_gather_tagged_rows(rows, mine, max(len(a) for a in assign), len(costs))
+assert table.shape == (13, 3) and torch.equal(table[:, 0], torch.tensor(costs, dtype=torch.float32)), (rank, table)
+assert torch.equal(table[:, 1], torch.arange(13, dtype=torch.float32) * 0.5)
+owner = torch.empty(13); [owner.__setitem__(i, float(r)) for r, a in enumerate(assign) for i in a]
+assert torch.equal(table[:, 2], owner)
+try:   # a unit claimed by both ranks is refused
+    fx.all_gather_tagged_rows(torch.zeros((1, 3)), [0], 1, 2)
+    raise SystemExit("a unit present twice went through")
+except ValueError:
+    pass
+rep = fx.describe_ranks(10.0 + rank, f"dev{rank}")
+assert rep["ranks"] == world and rep["devices"] == [f"dev{r}" for r in range(world)] and rep["backend"] == "gloo"
+assert rep["ms_per_step_rank_min"] == 10.0 and rep["ms_per_step_rank_max"] == 10.0 + world - 1
 # one tall image as row bands: exact partial moments in the image's coordinates
 # (here from the oracle's integer arithmetic), one integer all-reduce of limbs
-import numpy as np
 from oracle import cpu_ref
 img = np.random.default_rng(3).integers(0, 256, (600, 90), dtype=np.uint8)
 y0, y1 = fx.band_range(600, rank, world)
@@ -216,6 +234,7 @@ def test_bench_gpus_flag_starts_its_own_ranks():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1 and lines[0]["dry_run"] is True and lines[0]["n_gpus"] == 2 and lines[0]["rows"] == 10
+    assert lines[0]["ranks"] == 2 and lines[0]["devices"] == ["cpu", "cpu"] and lines[0]["ms_per_step_rank_max"] == 2.0
     # the tail configuration's clouds: LPT keeps the ranks' point counts close
     import importlib.util
     spec = importlib.util.spec_from_file_location("fx_bench", ROOT / "bench.py")
