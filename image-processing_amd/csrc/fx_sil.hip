@@ -771,6 +771,13 @@ __device__ SilRuns sil_label(const uint32_t *m, int rows, int wc, SilDiv dv, int
     const int t = threadIdx.x;
     const int nw = rows * wc;
     const int per = (nw + FX_BLOCK - 1) / FX_BLOCK;
+#ifdef SIL_TIMING
+    __shared__ unsigned long long s_lt[8];
+#define SIL_LTICK(k) do { if (t == 0 && blockIdx.x == 0) s_lt[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SIL_LTICK(k)
+#endif
+    SIL_LTICK(0);
     __syncthreads();
     // (a thread's run counts are kept for the second loop when they are few: 224 x 224 views have seven words
     // per thread)
@@ -914,7 +921,35 @@ __device__ SilRuns sil_label(const uint32_t *m, int rows, int wc, SilDiv dv, int
                 again |= 1u << (step & 31);
         }
     };
-    auto flatten = [&]() {
+    // deep: the chains may be as long as the shape is tall (after round one); otherwise a link or two (after round
+    // two), which a round or two of pointer jumping settles
+    auto flatten = [&](bool deep) {
+#ifndef SIL_FLATTEN_JUMPING
+        if (deep && R.n <= SIL_RUNS_LDS) {
+            // Every run to its root in one sweep by the first wave.  A parent is always a smaller index, so with the
+            // runs taken 64 at a time in rising order every parent outside the window is a root already (one look-up);
+            // inside the window the lanes jump over each other's pointers in registers, six rounds for 64 runs.  No
+            // block barrier per round, and the rounds do not grow with the height of the shape.
+            if (t < FX_WAVE) {
+                for (int base = 0; base < R.n; base += FX_WAVE) {
+                    const int r = base + t;
+                    uint32_t p = r < R.n ? parent[r] : (uint32_t)r;
+#pragma unroll
+                    for (int round = 0; round < 6; round++) {
+                        const uint32_t q = (uint32_t)__shfl((int)p, (int)(p - (uint32_t)base) & (FX_WAVE - 1), FX_WAVE);
+                        p = p >= (uint32_t)base ? q : p;
+                    }
+                    if (p < (uint32_t)base)
+                        p = parent[p];
+                    if (r < R.n)
+                        parent[r] = p;
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+            return;
+        }
+#endif
         // every run to its root: pointer jumping, the depth halves per round
         for (int round = 0; round < 48; round++) {   // the depth halves per round: 17 rounds flatten any chain of 2^17 runs
             int changed = 0;
@@ -935,6 +970,7 @@ __device__ SilRuns sil_label(const uint32_t *m, int rows, int wc, SilDiv dv, int
     for (int r = t; r < R.n; r += FX_BLOCK)
         R.val[r] = 0xFFFFFFFFu;
     __syncthreads();
+    SIL_LTICK(1);
     contacts(true);
     __threadfence_block();
     __syncthreads();
@@ -943,15 +979,24 @@ __device__ SilRuns sil_label(const uint32_t *m, int rows, int wc, SilDiv dv, int
             parent[r] = R.val[r];
     __threadfence_block();
     __syncthreads();
-    flatten();
+    SIL_LTICK(2);
+    flatten(true);
+    SIL_LTICK(3);
     // round two: the other contacts
     contacts(false);
     __threadfence_block();
     __syncthreads();
-    flatten();
+    SIL_LTICK(4);
+    flatten(false);
+    SIL_LTICK(5);
     for (int r = t; r < R.n; r += FX_BLOCK)
         R.val[r] = 0u;
     __syncthreads();
+#ifdef SIL_TIMING
+    if (t == 0 && blockIdx.x == 0)
+        printf("label: runs %d  scan %llu contacts1 %llu flatten1 %llu contacts2 %llu flatten2 %llu\n", R.n, s_lt[1] - s_lt[0],
+               s_lt[2] - s_lt[1], s_lt[3] - s_lt[2], s_lt[4] - s_lt[3], s_lt[5] - s_lt[4]);
+#endif
     return R;
 }
 

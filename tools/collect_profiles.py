@@ -79,6 +79,14 @@ def main():
                     "algorithmic bytes should be 1; a factor of 1 would give about 0.5, a wrong request mix something else",
             "traffic_over_algorithmic": hbm / (units * bytes_per_unit)},
     }
+    if workload == "c5":
+        # the clouds' passes: points and codes are read with 16 B/lane loads as well (same correction)
+        cloud = [k for k in kernels if k.startswith("cloud_")]
+        cloud_bytes = 338757828   # bench.py's "cloud_bytes_rank0" for this workload on one GPU
+        rd = sum(2.0 * kernels[k]["FETCH_SIZE"] * 1024.0 for k in cloud)
+        wr = sum(kernels[k]["WRITE_SIZE"] * 1024.0 for k in cloud)
+        doc["cloud_passes"] = {"kernels": cloud, "cloud_bytes": cloud_bytes, "read_bytes": rd, "written_bytes": wr,
+                               "read_over_cloud_bytes": rd / cloud_bytes}
     (round_dir / f"{workload}_pmc_hbm.json").write_text(json.dumps(doc, indent=1))
     tfile = ROOT / "profiles" / "traffic.json"
     traffic = json.loads(tfile.read_text()) if tfile.exists() else {}
