@@ -49,6 +49,11 @@ SIGNATURES = {
     "fx_read_npy_points_f32": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_int]),
     "fx_write_npy_rows_f32": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int]),
     "fx_decode_png_gray_u8": (c_int, [c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int]),
+    "fx_png_stage_bytes": (c_i64, [c_void_p, c_i64, c_int]),
+    "fx_png_stage": (c_int, [c_void_p, c_i64, c_int, c_int, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p,
+                             c_void_p, c_void_p, c_int]),
+    "fx_png_inflate_gray_u8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p,
+                                       c_void_p]),
     "fx_column_thresholds_f64": (c_int, [c_void_p, c_i64, c_int, c_i64, c_void_p, c_int, c_int, ctypes.c_double, c_int,
                                          c_void_p, c_void_p, c_void_p, c_void_p]),
     "fx_binarize_ge_f64": (c_int, [c_void_p, c_i64, c_int, c_i64, c_void_p, c_void_p, c_void_p]),

@@ -227,7 +227,10 @@ inline int paeth(int a, int b, int c)
     return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
 }
 
-int decode_one_png(const char *path, int want_h, int want_w, uint8_t *out, int32_t *found_hw)
+// Reads and checks a PNG file's container: signature, chunk CRCs, IHDR (size into found_hw, channel count), and
+// the IDAT payloads joined into `idat` (the zlib stream).
+int parse_one_png(const char *path, int want_h, int want_w, int32_t *found_hw, int *channels_out,
+                  std::vector<unsigned char> &idat)
 {
     const int fd = open(path, O_RDONLY | O_CLOEXEC);
     if (fd < 0)
@@ -248,7 +251,7 @@ int decode_one_png(const char *path, int want_h, int want_w, uint8_t *out, int32
     size_t pos = 8;
     int width = 0, height = 0, channels = 0;
     bool have_ihdr = false, have_iend = false;
-    std::vector<unsigned char> idat;
+    idat.clear();
     while (pos + 12 <= file.size()) {
         const uint32_t len = be32(&file[pos]);
         const unsigned char *type = &file[pos + 4];
@@ -289,6 +292,18 @@ int decode_one_png(const char *path, int want_h, int want_w, uint8_t *out, int32
     }
     if (!have_ihdr || !have_iend || idat.empty())
         return FX_IO_EFORMAT;
+    *channels_out = channels;
+    return FX_IO_OK;
+}
+
+int decode_one_png(const char *path, int want_h, int want_w, uint8_t *out, int32_t *found_hw)
+{
+    std::vector<unsigned char> idat;
+    int channels = 0;
+    const int st = parse_one_png(path, want_h, want_w, found_hw, &channels, idat);
+    if (st != FX_IO_OK)
+        return st;
+    const int width = want_w, height = want_h;
     const size_t stride = (size_t)width * channels;
     std::vector<unsigned char> raw((size_t)height * (stride + 1));
     uLongf raw_len = (uLongf)raw.size();
@@ -410,5 +425,60 @@ extern "C" int fx_decode_png_gray_u8(const char *const *paths, int64_t n, int H,
         found_hw[2 * i] = found_hw[2 * i + 1] = -1;
         status[i] = decode_one_png(paths[i], H, W, out + (size_t)i * H * W, found_hw + 2 * i);
     });
+    return FX_OK;
+}
+
+// Upper bound of the staging bytes fx_png_stage needs for these files (their sizes plus the padding per file).
+extern "C" int64_t fx_png_stage_bytes(const char *const *paths, int64_t n, int n_threads)
+{
+    if (n < 0 || (n > 0 && !paths))
+        return -1;
+    std::atomic<int64_t> total(0);
+    parallel_for(n, n_threads, [&](int64_t i) {
+        struct stat sb;
+        if (stat(paths[i], &sb) == 0 && sb.st_size > 0)
+            total.fetch_add(((int64_t)sb.st_size + 63) & ~(int64_t)15);
+        else
+            total.fetch_add(64);
+    });
+    return total.load() + 64;
+}
+
+extern "C" int fx_png_stage(const char *const *paths, int64_t n, int H, int W, uint8_t *staging, int64_t capacity,
+                            int64_t *offset, int32_t *length, int32_t *channels, int32_t *status, int32_t *found_hw,
+                            int64_t *used, int n_threads)
+{
+    if (n < 0 || H < 1 || W < 1 || capacity < 0 ||
+        (n > 0 && (!paths || !staging || !offset || !length || !channels || !status || !found_hw))) {
+        fx_set_error("fx_png_stage: bad arguments (n = %lld, %dx%d)", (long long)n, H, W);
+        return FX_EINVAL;
+    }
+    std::atomic<int64_t> at(0);
+    parallel_for(n, n_threads, [&](int64_t i) {
+        found_hw[2 * i] = found_hw[2 * i + 1] = -1;
+        offset[i] = 0;
+        length[i] = 0;
+        channels[i] = 0;
+        std::vector<unsigned char> idat;
+        int ch = 0;
+        int st = parse_one_png(paths[i], H, W, found_hw + 2 * i, &ch, idat);
+        if (st == FX_IO_OK) {
+            // the stream starts 16-byte aligned and is followed by at least 16 zero bytes: the device reads words
+            const int64_t need = (((int64_t)idat.size() + 15) & ~(int64_t)15) + 16;
+            const int64_t o = at.fetch_add(need);
+            if (idat.size() > (size_t)0x7fffffff || o + need > capacity) {
+                st = FX_IO_ENOSPACE;
+            } else {
+                memcpy(staging + o, idat.data(), idat.size());
+                memset(staging + o + idat.size(), 0, (size_t)(need - (int64_t)idat.size()));
+                offset[i] = o;
+                length[i] = (int32_t)idat.size();
+                channels[i] = ch;
+            }
+        }
+        status[i] = st;
+    });
+    if (used)
+        *used = at.load() < capacity ? at.load() : capacity;
     return FX_OK;
 }

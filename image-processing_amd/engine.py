@@ -8,6 +8,7 @@ from __future__ import annotations
 
 from typing import Optional
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -481,6 +482,33 @@ def profile_last_ms() -> float:
     """Milliseconds the kernels of the last hu_batch / pca_batch call took
     (waits for them); negative when profiling was off."""
     return float(_lib.load().fx_profile_last_ms())
+
+
+def png_inflate_batch(staged: dict, H: int, W: int, device) -> dict:
+    """Second half of the device decode of PNG files (ingest.stage_png_batch is the first): copies the staged zlib
+    streams to the device and inflates, unfilters and converts them there.  Only the files whose stage status is 0
+    take part.  {"gray": uint8 [m, H, W] on the device, "rows": int64 [m] positions of those files in the staged
+    batch, "status": int32 [m] on the device (0 = decoded; the others are for the host decoders)} -- byte for byte
+    what PIL's Image.open(path).convert("L") gives for the decoded ones."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise ValueError("png_inflate_batch needs a HIP device")
+    stream = _enter(device)
+    rows = np.nonzero(staged["status"] == 0)[0].astype(np.int64)
+    m = len(rows)
+    gray = torch.empty((m, int(H), int(W)), dtype=torch.uint8, device=device)
+    status = torch.zeros(m, dtype=torch.int32, device=device)
+    if m:
+        d_z = staged["staging"][: staged["used"]].to(device, non_blocking=True)
+        meta = torch.from_numpy(np.concatenate([staged["offset"][rows], staged["length"][rows].astype(np.int64),
+                                                staged["channels"][rows].astype(np.int64)]))
+        meta = (meta.pin_memory() if torch.cuda.is_available() else meta).to(device, non_blocking=True)
+        d_off = meta[:m].contiguous()
+        d_len = meta[m:2 * m].to(torch.int32)
+        d_ch = meta[2 * m:].to(torch.int32)
+        _lib.call("fx_png_inflate_gray_u8", d_z.data_ptr(), d_off.data_ptr(), d_len.data_ptr(), d_ch.data_ptr(), m,
+                  int(H), int(W), gray.data_ptr(), status.data_ptr(), stream)
+    return {"gray": gray, "rows": rows, "status": status}
 
 
 def profile_ms_back(back: int) -> float:

@@ -25,6 +25,7 @@ from __future__ import annotations
 import argparse
 import datetime
 import logging
+import os
 import sys
 from pathlib import Path
 from typing import Any, Dict, Iterable, List, Optional, Sequence, Tuple
@@ -235,12 +236,26 @@ def _log_error(reports_dir: Path, where, kind: str, msg) -> None:
         pass
 
 
+def png_on_device() -> bool:
+    """PNG views are inflated on the device (FX_PNG_DEVICE=0 in the environment keeps the decode on the host's
+    threads, as for every other file type)."""
+    if os.environ.get("FX_PNG_DEVICE", "1") == "0":
+        return False
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
 def decode_samples(tasks: Iterable[Tuple[str, str, Dict[str, Any]]], workers: Optional[int] = None) -> Dict[str, Any]:
     """Host half of process_samples: lists every task's views and decodes
     them.  PNG files of the batch's common size go through the native batch
-    decoder straight into one page-locked block; every other file (another
-    size or format, anything the native decoder does not take) is opened with
-    PIL on a thread pool.  Views that fail to load are logged to
+    path: their zlib streams are staged in one page-locked block for the
+    device to inflate (png_on_device), or they are decoded by native threads
+    straight into such a block; every other file (another size or format,
+    anything the native path does not take) is opened with PIL on a thread
+    pool.  Views that fail to load are logged to
     <reports_dir>/read_errors.log and skipped; a task whose directory cannot be
     listed is marked failed."""
     from . import ingest
@@ -276,10 +291,19 @@ def decode_samples(tasks: Iterable[Tuple[str, str, Dict[str, Any]]], workers: Op
         size = ingest.image_size(jobs[j][1])
         if size:
             break
-    block = owner = None
+    block = owner = staged = None
     native_ok = np.zeros(len(jobs), dtype=bool)
     row_of = {}
-    if size and png:
+    if size and png and png_on_device():
+        # the files' zlib streams go to the device as they are; inflate and row filters run there (finish_samples)
+        staged = ingest.stage_png_batch([str(jobs[j][1]) for j in png], size[0], size[1], workers)
+        r = 0
+        for k, j in enumerate(png):
+            if staged["status"][k] == 0:
+                native_ok[j] = True
+                row_of[j] = r
+                r += 1
+    elif size and png:
         block, owner = ingest.host_buffer((len(png), size[0], size[1]), np.uint8)
         status, _found = ingest.decode_png_batch([str(jobs[j][1]) for j in png], size[0], size[1], block, workers)
         for r, j in enumerate(png):
@@ -304,7 +328,7 @@ def decode_samples(tasks: Iterable[Tuple[str, str, Dict[str, Any]]], workers: Op
     block_owners = [jobs[j][0] for j in in_block]
     return {"tasks": tasks, "results": results, "views": views, "owners": owners, "keys": keys, "seq": seq,
             "paths": [str(v) for _, v in jobs],
-            "workers": workers, "block": block, "block_owner_tensor": owner,
+            "workers": workers, "block": block, "block_owner_tensor": owner, "staged": staged, "block_size": size,
             "block_rows": [row_of[j] for j in in_block], "block_owners": block_owners,
             "block_keys": [key_of(k, size) for k in block_owners], "block_seq": in_block}
 
@@ -333,6 +357,26 @@ def finish_samples(decoded: Dict[str, Any]) -> List[Dict[str, Any]]:
             usable = np.ones(len(order), dtype=bool)     # per row of rows_all: its view went through
             d_block = None
             nb = len(b_rows)
+            if decoded.get("staged") is not None and nb:
+                # inflate + row filters of the staged PNG streams; a stream the device declines goes to PIL, and a
+                # view PIL cannot read either is logged and left out, as any view that fails to load
+                H0, W0 = decoded["block_size"]
+                got = engine.png_inflate_batch(decoded["staged"], H0, W0, dev)
+                d_block = got["gray"]
+                declined = np.nonzero(got["status"].cpu().numpy())[0]
+                row_to_pos = {r: i for i, r in enumerate(b_rows)}
+                for r in declined.tolist():
+                    i = row_to_pos[r]
+                    j = decoded["block_seq"][i]
+                    try:
+                        img = load_image(Path(decoded["paths"][j]))
+                        if img.shape != (H0, W0):
+                            raise ValueError(f"view of {img.shape}, expected {(H0, W0)}")
+                        d_block[r] = torch.from_numpy(np.ascontiguousarray(img)).to(dev)
+                    except Exception as e:
+                        usable[rank[i]] = False
+                        _log_error(Path(tasks[b_owners[i]][2].get("reports_dir", "reports")), decoded["paths"][j],
+                                   type(e).__name__, e)
             # one pass per distinct (view size, settings): normally a single one
             for key in sorted(set(keys) | set(b_keys)):
                 idx = [i for i, kk in enumerate(keys) if kk == key]

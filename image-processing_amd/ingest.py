@@ -134,6 +134,36 @@ def decode_png_batch(paths: Sequence[str], H: int, W: int, out: np.ndarray, work
     return status, found
 
 
+def stage_png_batch(paths: Sequence[str], H: int, W: int, workers: int) -> dict:
+    """First half of the device decode of H x W PNG files: host threads read the files, check the container (as
+    decode_png_batch does) and copy every file's zlib stream into one page-locked block.  Returns {"staging"
+    (uint8 tensor, host), "used" (bytes of it written), "offset" int64 [n], "length" int32 [n], "channels" int32 [n],
+    "status" int32 [n] (0 = staged; anything else = left to the host decoders), "found" int32 [n, 2]}; the second
+    half is engine.png_inflate_batch."""
+    import ctypes
+    import torch
+    from . import _lib
+    n = len(paths)
+    out = {"offset": np.zeros(n, dtype=np.int64), "length": np.zeros(n, dtype=np.int32),
+           "channels": np.zeros(n, dtype=np.int32), "status": np.zeros(n, dtype=np.int32),
+           "found": np.full((n, 2), -1, dtype=np.int32), "used": 0,
+           "staging": torch.empty(0, dtype=torch.uint8)}
+    if n == 0:
+        return out
+    arr = _path_array(paths)
+    cap = int(_lib.load().fx_png_stage_bytes(arr, n, int(workers)))
+    if cap < 0:
+        raise ValueError("fx_png_stage_bytes: bad arguments")
+    staging = torch.empty(cap, dtype=torch.uint8, pin_memory=torch.cuda.is_available())
+    used = ctypes.c_int64(0)
+    _lib.call("fx_png_stage", arr, n, int(H), int(W), staging.data_ptr(), cap, out["offset"].ctypes.data,
+              out["length"].ctypes.data, out["channels"].ctypes.data, out["status"].ctypes.data, out["found"].ctypes.data,
+              ctypes.addressof(used), int(workers))
+    out["staging"] = staging
+    out["used"] = int(used.value)
+    return out
+
+
 def image_size(path):
     """(height, width) from the file header, or None."""
     try:

@@ -322,6 +322,7 @@ int fx_allgather_features(const void *d_local, int64_t local_rows, int row_float
 #define FX_IO_ESHAPE 5   /* not 2-D with at least 3 columns */
 #define FX_IO_EROWS 6    /* readable, but not of the batch's common size (the found size is reported) */
 #define FX_IO_EWIDE 7    /* float64 samples that float32 does not hold exactly: to be evaluated as float64 */
+#define FX_IO_ENOSPACE 8 /* fx_png_stage: the staging buffer is full */
 
 /*
  * Batch form of load_sample, src/features/extract_3d_pca_features.py:48-56
@@ -361,6 +362,38 @@ int fx_write_npy_rows_f32(const char *const *paths, int64_t n, const float *data
 int fx_decode_png_gray_u8(const char *const *paths, int64_t n, int H, int W,
                           uint8_t *out, int32_t *status, int32_t *found_hw,
                           int n_threads);
+
+/*
+ * The same decode with the inflate and the row filters on the device (no
+ * counterpart in the reference, whose load_image decodes on the host; the
+ * results are those of fx_decode_png_gray_u8 byte for byte).  Two steps:
+ *
+ * fx_png_stage (host threads) reads the files, checks the container exactly as
+ * fx_decode_png_gray_u8 does (signature, chunk CRCs, IHDR: 8 bits per sample,
+ * gray / gray+alpha / RGB / RGBA, not interlaced, no tRNS / PLTE, H x W) and
+ * copies each file's zlib stream (its IDAT payloads joined) into `staging`
+ * (host memory, page-locked if the copy to the device is to be asynchronous;
+ * fx_png_stage_bytes gives a sufficient capacity): offset[i] (16-byte aligned,
+ * at least 16 zero bytes behind the stream), length[i], channels[i], status[i]
+ * (FX_IO_*; FX_IO_ENOSPACE when `capacity` is used up), found_hw as above;
+ * *used = staging bytes written.
+ *
+ * fx_png_inflate_gray_u8 (device) takes the staged bytes in device memory with
+ * the three arrays of the files to decode (device memory, n entries; files
+ * whose stage status is not FX_IO_OK are left out by the caller) and writes
+ * d_out[i] (n x H x W uint8) and d_status[i]: 0, or a non-zero code for a
+ * stream it does not decode to exactly H rows of filter byte + W * channels
+ * bytes with a matching Adler-32 (damaged data, a preset dictionary, a
+ * filter type above 4): such a file is the caller's to hand to the host
+ * decoder or PIL, like any other status.  W * channels <= 4096.
+ */
+int64_t fx_png_stage_bytes(const char *const *paths, int64_t n, int n_threads);
+int fx_png_stage(const char *const *paths, int64_t n, int H, int W, uint8_t *staging, int64_t capacity,
+                 int64_t *offset, int32_t *length, int32_t *channels, int32_t *status, int32_t *found_hw,
+                 int64_t *used, int n_threads);
+int fx_png_inflate_gray_u8(const uint8_t *d_staged, const int64_t *d_offset, const int32_t *d_length,
+                           const int32_t *d_channels, int64_t n, int H, int W, uint8_t *d_out, int32_t *d_status,
+                           void *stream);
 
 /*
  * Per-column binarisation thresholds of a feature table: fit_thresholds,

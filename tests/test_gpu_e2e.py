@@ -140,6 +140,44 @@ def test_hu_directory_run_mixed_files(gpu, tmp_path, oracle, c_oracle, hu_panels
             np.testing.assert_allclose(got[7:], want[7:], rtol=1e-4, atol=1e-6)
 
 
+def test_png_inflated_on_the_device_equals_the_host_decode(gpu, tmp_path, hu_panels, monkeypatch):
+    """The directory run with the PNG streams inflated on the device (the default) and with FX_PNG_DEVICE=0 (native
+    host threads) writes the same table; a PNG whose pixel stream is damaged behind an intact container is declined
+    by the device, fails in PIL too, is logged and left out in both runs."""
+    import struct
+    import zlib
+    from PIL import Image
+    hu = pkg("extract_2d_hu")
+    raw = hu_panels["raw_views"]
+    views = tmp_path / "views"
+    for s in range(6):
+        d = views / f"tree_{s:02d}"
+        d.mkdir(parents=True)
+        for v in range(4):
+            img = Image.fromarray(raw[s % raw.shape[0], v % raw.shape[1]])
+            (img if (s + v) % 3 else img.convert("RGB")).save(d / f"view_{v + 1:02d}.png", compress_level=(s + v) % 10)
+    # damage one file's zlib stream (last byte of its Adler-32) and repair the chunk's CRC
+    victim = views / "tree_03" / "view_02.png"
+    data = bytearray(victim.read_bytes())
+    at = data.rindex(b"IDAT")
+    n = struct.unpack(">I", data[at - 4:at])[0]
+    data[at + 4 + n - 1] ^= 0x55
+    data[at + 4 + n:at + 8 + n] = struct.pack(">I", zlib.crc32(bytes(data[at:at + 4 + n])) & 0xFFFFFFFF)
+    victim.write_bytes(bytes(data))
+    tables = []
+    for tag, flag in (("dev", "1"), ("host", "0")):
+        monkeypatch.setenv("FX_PNG_DEVICE", flag)
+        out, rep = tmp_path / f"out_{tag}", tmp_path / f"rep_{tag}"
+        assert hu.main(["--views_dir", str(views), "--out_dir", str(out), "--reports_dir", str(rep), "--preprocess_crop",
+                        "--use_silhouette", "--expected_views", "4", "--overwrite"]) == 0
+        tables.append(pd.read_csv(out / "hu_features_table.csv").set_index("id"))
+        assert "view_02.png" in (rep / "read_errors.log").read_text()
+    a, b = tables
+    assert list(a.index) == list(b.index) and len(a) == 6
+    np.testing.assert_array_equal(a[hu.HU_COLS[1:15]].to_numpy(), b[hu.HU_COLS[1:15]].to_numpy())
+    assert list(a["note"]) == list(b["note"])
+
+
 def test_allgather_features_on_a_one_rank_communicator(gpu):
     """fx_allgather_features with an RCCL communicator made by the caller (one
     rank here; the N-rank case is the same call)."""

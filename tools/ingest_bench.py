@@ -27,11 +27,12 @@ from PIL import Image
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--samples", type=int, default=400)
+    ap.add_argument("--samples", type=int, default=2000)
     ap.add_argument("--views", type=int, default=12)
     ap.add_argument("--clouds", type=int, default=20000)
     ap.add_argument("--workers", type=int, default=16)
     ap.add_argument("--dir", default=None)
+    ap.add_argument("--batch_samples", type=int, default=256)
     a = ap.parse_args()
 
     eng = importlib.import_module("image-processing_amd.engine")
@@ -73,11 +74,26 @@ def main():
         eng.pca_batch(torch.zeros((2, 1024, 3), device=dev))
         torch.cuda.synchronize()
 
-        out = {"views": n_img, "clouds": a.clouds, "workers": a.workers, "png_bytes": png_bytes}
+        out = {"views": n_img, "clouds": a.clouds, "workers": a.workers, "png_bytes": png_bytes,
+               "batch_samples": a.batch_samples, "png_on_device": hu.png_on_device()}
+        import pandas  # noqa: F401  (0.3 s of imports that main() would otherwise do inside the timed call)
+        import yaml  # noqa: F401
+        # the two halves of a batch on their own: host (list, read, decode or stage) and device (+ descriptor files)
+        cfg = {"out_dir": str(root / "hu_probe"), "resolution": 224, "use_silhouette": True, "preprocess_crop": True,
+               "crop_margin": 0.05, "bg_color": "white", "expected_views": a.views, "overwrite": True,
+               "reports_dir": str(root / "rep")}
+        probe = [(f"tree_{s:05d}", str(views / f"tree_{s:05d}"), cfg) for s in range(min(a.samples, 256))]
+        hu.process_samples(probe[:8], a.workers)
+        t0 = time.perf_counter()
+        decoded = hu.decode_samples(probe, a.workers)
+        t1 = time.perf_counter()
+        hu.finish_samples(decoded)
+        t2 = time.perf_counter()
+        out["batch_of_256_samples"] = {"views": len(probe) * a.views, "host_half_seconds": t1 - t0, "device_half_seconds": t2 - t1}
         t0 = time.perf_counter()
         rc = hu.main(["--views_dir", str(views), "--out_dir", str(root / "hu"), "--reports_dir", str(root / "rep"),
                       "--use_silhouette", "--preprocess_crop", "--overwrite", "--workers", str(a.workers),
-                      "--batch_samples", "256"])
+                      "--batch_samples", str(a.batch_samples)])
         t_hu = time.perf_counter() - t0
         assert rc == 0
         out["hu_seconds"] = t_hu

@@ -101,6 +101,36 @@ if __name__ == "__main__":
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 5 * 1e3
         print(f"{what} pca 64 clouds, {int(off[-1])} points (1e4..4e6 each): {dt:.3f} ms  {off[-1]*12/dt/1e6:.0f} GB/s of input", flush=True)
+    elif what == "png":
+        # PNG files -> gray views on the device: staging on host threads, inflate + filters on the device, and the
+        # host decoder on the same threads for comparison
+        import numpy as np, tempfile, shutil, os
+        from pathlib import Path
+        from PIL import Image
+        ingest = importlib.import_module("image-processing_amd.ingest")
+        n, workers = int(os.environ.get("KB_PNG_N", "3072")), int(os.environ.get("KB_PNG_WORKERS", "16"))
+        root = Path(tempfile.mkdtemp(prefix="fx_png_"))
+        try:
+            views = gray_views(256, 224, 224).cpu().numpy()
+            flat = np.where(views > 128, 255, 30).astype(np.uint8)   # renderer-like: two flat levels
+            for kind, arr in (("noisy", views), ("flat", flat)):
+                for k in range(256):
+                    Image.fromarray(arr[k]).save(root / f"{kind}_{k:03d}.png")
+                paths = [str(root / f"{kind}_{k % 256:03d}.png") for k in range(n)]
+                size = sum(os.path.getsize(p) for p in paths[:256]) / 256
+                ingest.stage_png_batch(paths[:64], 224, 224, workers)
+                t0 = time.perf_counter(); staged = ingest.stage_png_batch(paths, 224, 224, workers); t_stage = time.perf_counter() - t0
+                eng.png_inflate_batch(staged, 224, 224, dev); torch.cuda.synchronize()
+                t0 = time.perf_counter(); got = eng.png_inflate_batch(staged, 224, 224, dev); torch.cuda.synchronize(); t_dev = time.perf_counter() - t0
+                eng.profile(True); eng.png_inflate_batch(staged, 224, 224, dev); k_ms = eng.profile_last_ms(); eng.profile(False)
+                host = np.empty((n, 224, 224), dtype=np.uint8)
+                t0 = time.perf_counter(); ingest.decode_png_batch(paths, 224, 224, host, workers); t_host = time.perf_counter() - t0
+                ok = bool((got["status"] == 0).all()) and bool((got["gray"].cpu().numpy() == host).all())
+                print(f"png {kind} {n} x 224x224 ({size/1e3:.1f} KB each), {workers} host threads: stage {n/t_stage/1e3:.1f} k files/s, "
+                      f"copy + device decode {t_dev*1e3:.2f} ms ({n/t_dev/1e3:.0f} k views/s; kernels {k_ms:.2f} ms), "
+                      f"host decode {n/t_host/1e3:.1f} k views/s; equal {ok}", flush=True)
+        finally:
+            shutil.rmtree(root, ignore_errors=True)
     elif what == "hu1k":
         for (B,H,W,c) in [(7500,1024,1024,False),(7500,1024,1024,True),(30000,512,512,True),(60000,512,256,True)]:
             ms, gbps = time_hu(B,H,W,c)

@@ -9,7 +9,7 @@ mkdir -p ../../build_dbg
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function"
 hipcc $F "$@" -c $src.hip -o ../../build_dbg/${src}_$name.o
 others=""
-for o in fx_api fx_bin fx_fps fx_hu fx_pca fx_render fx_sil fx_synth fx_io; do
+for o in fx_api fx_bin fx_fps fx_hu fx_pca fx_png fx_render fx_sil fx_synth fx_io; do
     [ $o = $src ] || others="$others $o.o"
 done
 hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build_dbg/libfx_$name.so $others ../../build_dbg/${src}_$name.o -lpthread -lz -ldl
