@@ -28,6 +28,7 @@ struct PngArgs {
     int H, W;
     int max_ch;                  // channels a row of W pixels may have (PNG_MAX_ROW bytes of LDS per row)
     uint8_t *raw;
+    uint32_t *adler;             // [n] the Adler-32 a stream ends with (checked where the bytes are read next)
     uint8_t *out;
     int32_t *status;
 };
@@ -170,7 +171,10 @@ __device__ __forceinline__ bool build_code(const uint8_t *lens, int n, uint16_t 
     return true;
 }
 
-// A wave per file.  Output: the file's H rows of (filter byte, W * channels bytes) in `raw`, its status.
+constexpr int COPY_TOGETHER = 16;   // matches of at least this many bytes are copied by all lanes at once
+
+// A wave per file.  Output: the file's H rows of (filter byte, W * channels bytes) in `raw`, the Adler-32 its stream
+// closes with, its status.
 __global__ __launch_bounds__(FX_WAVE) void png_inflate_kernel(PngArgs A)
 {
     __shared__ InflateLds L;
@@ -203,8 +207,8 @@ __global__ __launch_bounds__(FX_WAVE) void png_inflate_kernel(PngArgs A)
     br.next = 0;
     br.ring = L.ring;
     int64_t op = 0;            // bytes written
-    uint32_t a1 = 1, a2 = 0;   // Adler-32 of them
     int status = PNG_OK;
+    int copy_len = 0, copy_dist = 0;   // a long match that lane 0 has met: the wave copies it at the top of the loop
     int phase = 0;             // 0: at a block header, 1: in a coded block, 2: in a stored block, 3: after the last block
     int last = 0;              // the block in hand is the final one
     int stored_left = 0;
@@ -228,7 +232,22 @@ __global__ __launch_bounds__(FX_WAVE) void png_inflate_kernel(PngArgs A)
         status = __builtin_amdgcn_readfirstlane(status);
         phase = __builtin_amdgcn_readfirstlane(phase);
         setup = __builtin_amdgcn_readfirstlane(setup);
-        if (status != PNG_OK || phase == 3)
+        copy_len = __builtin_amdgcn_readfirstlane(copy_len);
+        if (status != PNG_OK)
+            break;
+        if (copy_len > 0) {
+            // Byte k of the match is byte (k mod dist) of the dist bytes in front of it: all of them written already,
+            // so the lanes copy side by side (one trip to memory for the match instead of one per byte).
+            const int dist = __builtin_amdgcn_readfirstlane(copy_dist);
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)op);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((u64)op >> 32));
+            const int64_t at = (int64_t)(((u64)hi << 32) | lo);
+            for (int k = lane; k < copy_len; k += FX_WAVE)
+                out[at + k] = out[at - dist + (dist >= copy_len ? k : k % dist)];
+            op = at + copy_len;
+            copy_len = 0;
+        }
+        if (phase == 3)
             break;
         {
             const uint32_t next = (uint32_t)__builtin_amdgcn_readfirstlane((int)br.next);
@@ -372,14 +391,7 @@ __global__ __launch_bounds__(FX_WAVE) void png_inflate_kernel(PngArgs A)
                     status = PNG_ELENGTH;
                     break;
                 }
-                const uint32_t v = br.take(8);
-                out[op++] = (uint8_t)v;
-                a1 += v;
-                a2 += a1;
-                if ((op & 4095) == 0) {
-                    a1 %= 65521u;
-                    a2 %= 65521u;
-                }
+                out[op++] = (uint8_t)br.take(8);
                 stored_left--;
             }
             if (stored_left == 0)
@@ -400,12 +412,6 @@ __global__ __launch_bounds__(FX_WAVE) void png_inflate_kernel(PngArgs A)
                     break;
                 }
                 out[op++] = (uint8_t)sym;
-                a1 += (uint32_t)sym;
-                a2 += a1;
-                if ((op & 4095) == 0) {
-                    a1 %= 65521u;
-                    a2 %= 65521u;
-                }
                 continue;
             }
             if (sym == 256) {
@@ -433,37 +439,34 @@ __global__ __launch_bounds__(FX_WAVE) void png_inflate_kernel(PngArgs A)
                 status = PNG_ELENGTH;
                 break;
             }
+            if (len >= COPY_TOGETHER) {
+                copy_len = len;
+                copy_dist = dist;
+                break;
+            }
             for (int k = 0; k < len; k++) {
-                const uint32_t v = out[op - dist];
-                out[op++] = (uint8_t)v;
-                a1 += v;
-                a2 += a1;
-                if ((op & 4095) == 0) {
-                    a1 %= 65521u;
-                    a2 %= 65521u;
-                }
+                out[op] = out[op - dist];
+                op++;
             }
         }
     }
 
     if (lane == 0) {
         if (status == PNG_OK) {
-            // the Adler-32 of the output, big-endian, from the next byte boundary on
+            // the Adler-32 of the output, big-endian, from the next byte boundary on (png_unfilter_kernel, which reads
+            // every byte anyway, sums them and compares)
             br.drop(br.cnt & 7);
             uint32_t stored = 0;
             for (int k = 0; k < 4; k++) {
                 br.fill();
                 stored = (stored << 8) | br.take(8);
             }
-            a1 %= 65521u;
-            a2 %= 65521u;
             const int64_t consumed = (int64_t)br.next * 4 - (br.cnt >> 3);
             if (op != want)
                 status = PNG_ELENGTH;
             else if (consumed > (int64_t)zlen)
                 status = PNG_EINPUT;
-            else if (stored != ((a2 << 16) | a1))
-                status = PNG_EADLER;
+            A.adler[f] = stored;
         }
         A.status[f] = status;
     }
@@ -491,13 +494,23 @@ __global__ __launch_bounds__(FX_WAVE) void png_unfilter_kernel(PngArgs A)
     const uint8_t *raw = A.raw + A.raw_offset[f];
     uint8_t *out = A.out + f * (int64_t)A.H * A.W;
     int bad = 0;
+    // Adler-32 of the inflated bytes b_0 .. b_{L-1}: low half 1 + sum b_i, high half L + sum (L - i) b_i, both
+    // mod 65521 (each lane sums its bytes in 64 bits: at most 255 * L^2 / 64 < 2^63)
+    const u64 L = (u64)A.H * (u64)(stride + 1);
+    u64 s1 = 0, s2 = 0;
     for (int y = 0; y < A.H; y++) {
         uint8_t *cur = rows[y & 1];
         const uint8_t *up = rows[(y & 1) ^ 1];
         const uint8_t *src = raw + (int64_t)y * (stride + 1);
         const int ft = src[0];
+        if (lane == 0) {
+            s1 += (u64)ft;
+            s2 += (L - (u64)y * (u64)(stride + 1)) * (u64)ft;
+        }
         for (int i = lane; i < stride; i += FX_WAVE) {
             int v = src[1 + i];
+            s1 += (u64)v;
+            s2 += (L - ((u64)y * (u64)(stride + 1) + 1u + (u64)i)) * (u64)v;
             if (ft == 2 && y > 0)
                 v += up[i];
             cur[i] = (uint8_t)v;
@@ -531,8 +544,15 @@ __global__ __launch_bounds__(FX_WAVE) void png_unfilter_kernel(PngArgs A)
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    if (bad && lane == 0)
-        A.status[f] = PNG_EFILTER;
+    s1 = fx_wave_sum_u64(s1);
+    s2 = fx_wave_sum_u64(s2 % 65521ull);
+    const uint32_t a1 = (uint32_t)((1ull + s1) % 65521ull), a2 = (uint32_t)((L + s2) % 65521ull);
+    if (lane == 0) {
+        if (bad)
+            A.status[f] = PNG_EFILTER;
+        else if (A.adler[f] != ((a2 << 16) | a1))
+            A.status[f] = PNG_EADLER;
+    }
 }
 
 // raw_offset[i] = sum over the files before i of H * (W * channels + 1): one block, files in chunks of 1024
@@ -597,7 +617,8 @@ extern "C" int fx_png_inflate_gray_u8(const uint8_t *d_staged, const int64_t *d_
     FX_REQUIRE(max_ch >= 1, "fx_png_inflate_gray_u8: rows of %d pixels are too long", W);
     const int64_t cap = n * (int64_t)H * ((int64_t)W * max_ch + 1);
     const size_t off_bytes = (((size_t)n + 1) * sizeof(int64_t) + 255) & ~(size_t)255;
-    unsigned char *base = (unsigned char *)guard.scratch(off_bytes + (size_t)cap, 3);
+    const size_t adler_bytes = ((size_t)n * sizeof(uint32_t) + 255) & ~(size_t)255;
+    unsigned char *base = (unsigned char *)guard.scratch(off_bytes + adler_bytes + (size_t)cap, 3);
     if (!base)
         return FX_ENOMEM;
     PngArgs A;
@@ -610,7 +631,8 @@ extern "C" int fx_png_inflate_gray_u8(const uint8_t *d_staged, const int64_t *d_
     A.H = H;
     A.W = W;
     A.max_ch = max_ch;
-    A.raw = base + off_bytes;
+    A.adler = (uint32_t *)(base + off_bytes);
+    A.raw = base + off_bytes + adler_bytes;
     A.out = d_out;
     A.status = d_status;
     hipLaunchKernelGGL(png_offsets_kernel, dim3(1), dim3(1024), 0, s, A, (int64_t *)base, cap);

@@ -508,6 +508,12 @@ def png_inflate_batch(staged: dict, H: int, W: int, device) -> dict:
         d_ch = meta[2 * m:].to(torch.int32)
         _lib.call("fx_png_inflate_gray_u8", d_z.data_ptr(), d_off.data_ptr(), d_len.data_ptr(), d_ch.data_ptr(), m,
                   int(H), int(W), gray.data_ptr(), status.data_ptr(), stream)
+    if staged.get("block") is not None:
+        from . import ingest
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(device))
+        ingest.release_staging(staged["block"], done)   # (the block may be staged into again once the copy is out)
+        staged["block"] = None
     return {"gray": gray, "rows": rows, "status": status}
 
 

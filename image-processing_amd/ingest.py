@@ -134,12 +134,38 @@ def decode_png_batch(paths: Sequence[str], H: int, W: int, out: np.ndarray, work
     return status, found
 
 
+# Page-locked staging blocks are kept and reused: locking host memory costs about as much per megabyte as reading
+# the files does.  A block is taken for a batch and given back with an event that tells when the copy out of it is done.
+_staging_blocks: list = []
+_staging_lock = threading.Lock()
+
+
+def take_staging(nbytes: int) -> dict:
+    import torch
+    with _staging_lock:
+        for e in _staging_blocks:
+            if not e["busy"] and e["t"].numel() >= nbytes and (e["event"] is None or e["event"].query()):
+                e["busy"] = True
+                return e
+        cap = max(int(nbytes * 1.25), 32 << 20)
+        e = {"t": torch.empty(cap, dtype=torch.uint8, pin_memory=torch.cuda.is_available()), "busy": True, "event": None}
+        if len(_staging_blocks) < 4:
+            _staging_blocks.append(e)
+        return e
+
+
+def release_staging(entry: dict, event=None) -> None:
+    with _staging_lock:
+        entry["event"] = event
+        entry["busy"] = False
+
+
 def stage_png_batch(paths: Sequence[str], H: int, W: int, workers: int) -> dict:
     """First half of the device decode of H x W PNG files: host threads read the files, check the container (as
     decode_png_batch does) and copy every file's zlib stream into one page-locked block.  Returns {"staging"
     (uint8 tensor, host), "used" (bytes of it written), "offset" int64 [n], "length" int32 [n], "channels" int32 [n],
-    "status" int32 [n] (0 = staged; anything else = left to the host decoders), "found" int32 [n, 2]}; the second
-    half is engine.png_inflate_batch."""
+    "status" int32 [n] (0 = staged; anything else = left to the host decoders), "found" int32 [n, 2], "block" (what
+    release_staging takes once the bytes have been copied out)}; the second half is engine.png_inflate_batch."""
     import ctypes
     import torch
     from . import _lib
@@ -147,20 +173,22 @@ def stage_png_batch(paths: Sequence[str], H: int, W: int, workers: int) -> dict:
     out = {"offset": np.zeros(n, dtype=np.int64), "length": np.zeros(n, dtype=np.int32),
            "channels": np.zeros(n, dtype=np.int32), "status": np.zeros(n, dtype=np.int32),
            "found": np.full((n, 2), -1, dtype=np.int32), "used": 0,
-           "staging": torch.empty(0, dtype=torch.uint8)}
+           "staging": torch.empty(0, dtype=torch.uint8), "block": None}
     if n == 0:
         return out
     arr = _path_array(paths)
     cap = int(_lib.load().fx_png_stage_bytes(arr, n, int(workers)))
     if cap < 0:
         raise ValueError("fx_png_stage_bytes: bad arguments")
-    staging = torch.empty(cap, dtype=torch.uint8, pin_memory=torch.cuda.is_available())
+    block = take_staging(cap)
+    staging = block["t"]
     used = ctypes.c_int64(0)
     _lib.call("fx_png_stage", arr, n, int(H), int(W), staging.data_ptr(), cap, out["offset"].ctypes.data,
               out["length"].ctypes.data, out["channels"].ctypes.data, out["status"].ctypes.data, out["found"].ctypes.data,
               ctypes.addressof(used), int(workers))
     out["staging"] = staging
     out["used"] = int(used.value)
+    out["block"] = block
     return out
 
 
