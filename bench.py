@@ -424,25 +424,35 @@ def main(argv=None):
         rvm.render_views_device(flat, cloud_off, 12, 224)
         kernel_ms = [eng.profile_last_ms()]
     eng.profile(False)
-    ranks = fxdist.describe_ranks(elapsed / args.steps * 1e3, torch.cuda.get_device_name(dev))
+    # What follows describes the run; a failure in it must not cost the measurement (every rank takes the same path:
+    # the collectives inside are entered by all or by none).
+    own_ms = elapsed / args.steps * 1e3
     gather_ms = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        # the exchange step on its own: one all-gather of a step's feature rows with nothing beside it
-        rows = feats[0] if kind == "tail" else feats
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        fence()
-        e0.record()
-        if kind != "tail" and wl["scaling"] == "weak":
-            gather.submit(rows)
-            gather.drain()
-        else:
-            fxdist.all_gather_rows(rows, total)
-        e1.record()
-        torch.cuda.synchronize()
-        gather_ms = float(e0.elapsed_time(e1))
+    try:
+        ranks = fxdist.describe_ranks(own_ms, torch.cuda.get_device_name(dev))
+    except Exception as e:   # pragma: no cover
+        ranks = {"ranks": world, "ranks_error": f"{type(e).__name__}: {e}"}
+    if world > 1:
+        try:
+            # the exchange step on its own: one all-gather of a step's feature rows with nothing beside it
+            rows = feats[0] if kind == "tail" else feats
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            fence()
+            e0.record()
+            if kind != "tail" and wl["scaling"] == "weak":
+                gather.submit(rows)
+                gather.drain()
+            else:
+                fxdist.all_gather_rows(rows, total)
+            e1.record()
+            torch.cuda.synchronize()
+            gather_ms = float(e0.elapsed_time(e1))
+        except Exception as e:   # pragma: no cover
+            ranks["all_gather_error"] = f"{type(e).__name__}: {e}"
 
     out = None
     if rank == 0:

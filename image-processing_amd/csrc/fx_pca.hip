@@ -1845,7 +1845,7 @@ __global__ __launch_bounds__(CLOUD_THREADS, 4) void cloud_proj_kernel(PcaArgs A,
 }
 
 template <typename T>
-__global__ __launch_bounds__(CLOUD_THREADS, 4) void cloud_hist_kernel(PcaArgs A, CloudWork Wk, int back)
+__global__ __launch_bounds__(CLOUD_THREADS, 8) void cloud_hist_kernel(PcaArgs A, CloudWork Wk, int back)
 {
     __shared__ uint32_t hist[CLOUD_WAVES * CLOUD_HIST_COPIES][CLOUD_HIST_PITCH];
     const int n = *Wk.n_chunks_dev;
