@@ -1997,6 +1997,7 @@ struct RaggedLists {
     CloudChunk *chunks;    // [max_chunks]
     CloudCtl *ctl;         // [max_clouds]
     int64_t max_clouds, max_chunks;
+    int64_t max_reg, max_lds;   // entries the launches over the register and the LDS list are sized for
     int64_t total;         // points behind the caller's pointer (CSR batches), or 0
 };
 
@@ -2049,10 +2050,11 @@ __global__ __launch_bounds__(CLASSIFY_THREADS) void pca_classify_kernel(PcaArgs 
         for (int w = 0; w < wave; w++)
             pos += wave_cnt[w][cls];
         int32_t *list = cls == 0 ? L.reg_ids : cls == 1 ? L.lds_ids : cls == 2 ? L.cloud_ids : L.quad_ids;
-        if (cls != 2 || pos < L.max_clouds)
+        const int64_t room = cls == 0 ? L.max_reg : cls == 1 ? L.max_lds : cls == 2 ? L.max_clouds : B;
+        if (pos < room)
             list[pos] = (int32_t)b;
         else
-            bad = true;   // more large clouds than the point count allows: the offsets overlap
+            bad = true;   // more sets of this size than the point count allows: the offsets overlap
     }
     if (bad)
         write_nan_row(A, b, 0, 1);
@@ -2273,6 +2275,17 @@ int launch_ragged_on_device(const PcaArgs &A, int64_t B, int64_t total, bool all
     p += redo_bytes;
     cloud_layout(p, max_clouds, max_chunks, L, Wk);
     L.total = A.offsets ? total : 0;
+    // The launches over the register and the LDS list are sized by what the point count allows: a set of the
+    // former has more than QUAD_MAX_POINTS points, one of the latter more than REG_SET_MAX_POINTS (a block that
+    // finds itself behind its list leaves at once, but a quarter of a million of them take 0.15 - 0.3 ms to start
+    // and leave).  The classification gives a set that finds its list full a NaN row: the offsets overlap.
+    auto bound = [&](int64_t more_than) {
+        const int64_t most = total / (more_than + 1);
+        return most < B ? (most > 1 ? most : 1) : B;
+    };
+    const int64_t reg_bound = bound(QUAD_MAX_POINTS), lds_bound = bound(REG_SET_MAX_POINTS);
+    L.max_reg = reg_bound;
+    L.max_lds = lds_bound;
 
     FX_HIP_CHECK(hipMemsetAsync(L.counts, 0, counts_bytes, s));
     const int64_t reg_max = REG_SET_MAX_POINTS;
@@ -2294,7 +2307,7 @@ int launch_ragged_on_device(const PcaArgs &A, int64_t B, int64_t total, bool all
     if (rc == FX_OK && !all_clouds) {
         PcaArgs S = A;
         S.set_ids = L.reg_ids;
-        S.n_sets = B;
+        S.n_sets = reg_bound;
         S.n_sets_dev = L.counts + 0;
         S.redo_count = L.counts + 17;
         S.redo_zeroed = 1;
@@ -2304,7 +2317,7 @@ int launch_ragged_on_device(const PcaArgs &A, int64_t B, int64_t total, bool all
     if (rc == FX_OK && !all_clouds) {
         PcaArgs S = A;
         S.set_ids = L.lds_ids;
-        S.n_sets = B;
+        S.n_sets = lds_bound;
         S.n_sets_dev = L.counts + 1;
         S.redo_count = L.counts + 18;
         S.redo_zeroed = 1;

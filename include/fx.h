@@ -147,7 +147,9 @@ int fx_hu_groupstat(const float *d_hulog7, const int64_t *d_group_offsets,
  *               wait for the stream.  N <= 0: unknown; the call copies the
  *               offsets to the host and waits for `stream` once before
  *               launching (and rejects decreasing offsets with FX_EINVAL,
- *               which the device path turns into NaN rows)
+ *               which the device path turns into NaN rows; with offsets that
+ *               go back and forth, sets that together cover more points than
+ *               N may get NaN rows too)
  *   n_bins      1..64 bins of the |projection on PC1| histogram
  *   normalize   != 0: divide centred points by their largest norm (:79-83)
  *   d_out       B x (9+n_bins) floats: lambda1..3, r1..3, ratio12, ratio23,

@@ -212,6 +212,28 @@ def test_point_count_smaller_than_the_offsets_say(gpu):
                 assert np.isnan(got[b]).all(), (cut, b, got[b])
 
 
+def test_offsets_that_overlap_cannot_overrun_a_list(gpu):
+    """The launches over the device-built lists are sized by the caller's point count.  Offsets that go back and
+    forth can name more sets of a size than that count has room for: the surplus gets NaN rows, the sets the
+    lists hold are computed as ever, nothing is read or written out of bounds."""
+    import torch
+    eng = pkg("engine")
+    rng = np.random.default_rng(5)
+    flat = torch.from_numpy(rng.normal(size=(3000, 3)).astype(np.float32)).to(gpu)
+    for n in (600, 1500, 2500):   # register list, LDS list, large clouds
+        B = 41
+        off = np.zeros(B + 1, dtype=np.int64)
+        off[1::2] = n                       # sets 0, 2, 4, ... are points 0 .. n; the odd ones run backwards
+        d_off = torch.from_numpy(off).to(gpu)
+        out = eng.pca_batch(flat, d_off, 8, False)["out"].cpu().numpy()
+        ref = eng.pca_batch(flat[:n].reshape(1, n, 3).contiguous(), None, 8, False)["out"].cpu().numpy()[0]
+        assert np.isnan(out[1::2]).all()
+        rows = out[0::2]
+        good = ~np.isnan(rows).any(axis=1)
+        assert 1 <= good.sum() <= len(rows) and (np.isnan(rows[~good])).all()
+        np.testing.assert_allclose(rows[good], np.broadcast_to(ref, rows[good].shape), rtol=1e-6, atol=1e-7)
+
+
 def test_full_size_properties(gpu):
     """C4-sized batch: invariants that need no CPU pass.  Rotating a cloud
     leaves the eigenvalues unchanged; the histogram sums to one; r1+r2+r3 = 1."""
