@@ -967,7 +967,8 @@ __global__ __launch_bounds__(FX_WAVE *NW, PPL > 16 ? 2 : (PPL <= 8 && !RAGGED) ?
 // listed point; the exact maximum of a row is an LDS atomic maximum over its listed points.  Sets that pass
 // cannot take (projections at rounding level, a list that overflows) go to the redo list.
 constexpr int QUAD_SETS = 4, QUAD_LANES = FX_WAVE / QUAD_SETS, QUAD_PPL = 16;
-constexpr int64_t QUAD_MAX_POINTS = QUAD_LANES * QUAD_PPL;
+constexpr int64_t QUAD_MAX_POINTS = QUAD_LANES * QUAD_PPL;   // with QUAD_PPL point slots per lane; the kernel also exists
+                                                             // with 8 and 4 slots, for sets of up to 128 and 64 points
 constexpr int QUAD_COPIES = 4, QUAD_PITCH = HIST_MAX + 1, QUAD_LIST_CAP = 96;
 struct QuadRec {
     double mean[3], v1[3], rmax;   // rmax = 0: no scaling
@@ -1007,25 +1008,27 @@ __device__ __forceinline__ uint32_t quad_row_max_u32(uint32_t v)
     return v;
 }
 
-template <int NW>
-__global__ __launch_bounds__(FX_WAVE *NW, 3) void pca_sets_quad_kernel(PcaArgs A, double inv_nb)
+// The LDS of a wave of the quad kernels.
+struct QuadLds {
+    uint32_t hist[QUAD_SETS * QUAD_COPIES * QUAD_PITCH];
+    float4 list[QUAD_LIST_CAP + FX_WAVE];
+    QuadRec rec[QUAD_SETS];
+    unsigned long long top[QUAD_SETS];
+};
+
+// One wave's work: the four sets from entry `first` of the list A.set_ids (n_sets entries; NULL: the sets
+// themselves), with PPL point slots per lane.
+template <int PPL>
+__device__ __forceinline__ void pca_sets_quad_body(const PcaArgs &A, QuadLds &W, const int64_t n_sets, const int64_t first, double inv_nb)
 {
-    __shared__ uint32_t hist_all[NW][QUAD_SETS * QUAD_COPIES * QUAD_PITCH];
-    __shared__ float4 list_all[NW][QUAD_LIST_CAP + FX_WAVE];
-    __shared__ QuadRec rec_all[NW][QUAD_SETS];
-    __shared__ unsigned long long top_all[NW][QUAD_SETS];
-    const int lane = fx_lane(), wave = fx_wave();
+    const int lane = fx_lane();
     const int row = lane / QUAD_LANES, r = lane % QUAD_LANES;
-    const int64_t n_sets = A.n_sets_dev ? (int64_t)*A.n_sets_dev : A.n_sets;
-    const int64_t first = ((int64_t)blockIdx.x * NW + wave) * QUAD_SETS;
-    if (first >= n_sets)
-        return;   // the whole wave; there is no block barrier below
     const int64_t slot = first + row;
     const bool in_range = slot < n_sets;
     const SetView sv = resolve_set(A, in_range ? slot : first);
     const int64_t set = sv.set;
     const int nb = A.n_bins, width = 9 + nb, dims = A.dims;
-    const bool small = sv.n <= QUAD_MAX_POINTS;
+    const bool small = sv.n <= QUAD_LANES * PPL;
     const bool live = in_range && sv.n >= 3 && small;
     const int n = live ? (int)sv.n : 0;
     if (in_range && sv.n < 3)
@@ -1036,7 +1039,7 @@ __global__ __launch_bounds__(FX_WAVE *NW, 3) void pca_sets_quad_kernel(PcaArgs A
     };
     to_redo(in_range && !small);   // (the dispatcher sends no such set here)
 
-    uint32_t *hist = hist_all[wave];
+    uint32_t *hist = W.hist;
     for (int k = lane; k < QUAD_SETS * QUAD_COPIES * QUAD_PITCH; k += FX_WAVE)
         hist[k] = 0;
     uint32_t *my_hist = hist + (row * QUAD_COPIES + (r % QUAD_COPIES)) * QUAD_PITCH;
@@ -1044,10 +1047,10 @@ __global__ __launch_bounds__(FX_WAVE *NW, 3) void pca_sets_quad_kernel(PcaArgs A
     // Lane r holds the points r, r + 16, ...; the slots past the end of the set hold the set's first point, which
     // is the pivot of the sums: such a slot adds exact zeros to them, and a copy of a point changes no maximum.
     // (No predicates until the histogram.)
-    float x[QUAD_PPL], y[QUAD_PPL], z[QUAD_PPL];
+    float x[PPL], y[PPL], z[PPL];
     float kx32 = 0.0f, ky32 = 0.0f, kz32 = 0.0f;
 #pragma unroll
-    for (int k = 0; k < QUAD_PPL; k++)
+    for (int k = 0; k < PPL; k++)
         x[k] = y[k] = z[k] = 0.0f;
     if (live) {
         struct P3 {
@@ -1058,7 +1061,7 @@ __global__ __launch_bounds__(FX_WAVE *NW, 3) void pca_sets_quad_kernel(PcaArgs A
         };
         if (dims == 3) {
 #pragma unroll
-            for (int k = 0; k < QUAD_PPL; k++) {
+            for (int k = 0; k < PPL; k++) {
                 const int p = r + QUAD_LANES * k;
                 const P3 v = *reinterpret_cast<const P3 *>(sv.base + 3 * (p < n ? p : 0));
                 x[k] = v.a, y[k] = v.b, z[k] = v.c;
@@ -1067,7 +1070,7 @@ __global__ __launch_bounds__(FX_WAVE *NW, 3) void pca_sets_quad_kernel(PcaArgs A
             kx32 = v.a, ky32 = v.b, kz32 = v.c;
         } else {   // 2-D points are (x, y, 0)
 #pragma unroll
-            for (int k = 0; k < QUAD_PPL; k++) {
+            for (int k = 0; k < PPL; k++) {
                 const int p = r + QUAD_LANES * k;
                 const P2 v = *reinterpret_cast<const P2 *>(sv.base + 2 * (p < n ? p : 0));
                 x[k] = v.a, y[k] = v.b;
@@ -1079,7 +1082,7 @@ __global__ __launch_bounds__(FX_WAVE *NW, 3) void pca_sets_quad_kernel(PcaArgs A
     const double kx = kx32, ky = ky32, kz = kz32;
     double v9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int k = 0; k < QUAD_PPL; k++) {
+    for (int k = 0; k < PPL; k++) {
         const double dx = (double)x[k] - kx, dy = (double)y[k] - ky, dz = (double)z[k] - kz;
         v9[0] += dx;
         v9[1] += dy;
@@ -1111,7 +1114,7 @@ __global__ __launch_bounds__(FX_WAVE *NW, 3) void pca_sets_quad_kernel(PcaArgs A
     if (A.normalize) {
         double r2 = 0.0;
 #pragma unroll
-        for (int k = 0; k < QUAD_PPL; k++) {
+        for (int k = 0; k < PPL; k++) {
             const double dx = (double)x[k] - mx, dy = (double)y[k] - my, dz = (double)z[k] - mz;
             r2 = fmax(r2, dx * dx + dy * dy + dz * dz);
         }
@@ -1155,7 +1158,7 @@ __global__ __launch_bounds__(FX_WAVE *NW, 3) void pca_sets_quad_kernel(PcaArgs A
     const float eps32 = 1e-6f * w32 * (2.0f * m1 + reach32) + 1e-37f;
     float top32 = 0.0f;
 #pragma unroll
-    for (int k = 0; k < QUAD_PPL; k++)
+    for (int k = 0; k < PPL; k++)
         top32 = fmaxf(top32, fabsf(fmaf(z[k], vz32, fmaf(y[k], vy32, fmaf(x[k], vx32, -c32)))));
     top32 = __int_as_float((int)quad_row_max_u32((uint32_t)__float_as_int(top32)));
     // rows whose projections are at rounding level are redone in float64 throughout
@@ -1165,12 +1168,12 @@ __global__ __launch_bounds__(FX_WAVE *NW, 3) void pca_sets_quad_kernel(PcaArgs A
     const float qx = vx32 * inv32, qy = vy32 * inv32, qz = vz32 * inv32, qc = c32 * inv32;
     const float margin = (3.0f * eps32 + 6e-7f * top32) * inv32 + 1e-5f * (float)nb;
     if (r == 0) {
-        QuadRec *rec = &rec_all[wave][row];
+        QuadRec *rec = &W.rec[row];
         rec->mean[0] = mx, rec->mean[1] = my, rec->mean[2] = mz;
         rec->v1[0] = v1[0], rec->v1[1] = v1[1], rec->v1[2] = v1[2];
         rec->rmax = scale ? rmax : 0.0;
         rec->q[0] = qx, rec->q[1] = qy, rec->q[2] = qz, rec->q[3] = qc;
-        top_all[wave][row] = 0ull;
+        W.top[row] = 0ull;
     }
     auto wave_sync = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1178,12 +1181,12 @@ __global__ __launch_bounds__(FX_WAVE *NW, 3) void pca_sets_quad_kernel(PcaArgs A
     };
     wave_sync();
     // one pass settles the bins of every point float32 can settle; the others are listed with their row
-    float4 *list = list_all[wave];
+    float4 *list = W.list;
     int n_slow = 0;
     bool overflow = false;
     const int n_act = act ? n : 0;
 #pragma unroll
-    for (int k = 0; k < QUAD_PPL; k++) {
+    for (int k = 0; k < PPL; k++) {
         const bool hv = r + QUAD_LANES * k < n_act;
         const float q = fabsf(fmaf(z[k], qz, fmaf(y[k], qy, fmaf(x[k], qx, -qc))));
         const bool slow = hv && fabsf(q - rintf(q)) < margin;
@@ -1220,12 +1223,12 @@ __global__ __launch_bounds__(FX_WAVE *NW, 3) void pca_sets_quad_kernel(PcaArgs A
     for (int e = lane; e < n_slow; e += FX_WAVE) {
         const float4 pt = list[e];
         const int er = __float_as_int(pt.w);
-        const double pv = proj(&rec_all[wave][er], pt.x, pt.y, pt.z);
-        atomicMax(&top_all[wave][er], (unsigned long long)__double_as_longlong(pv));   // pv >= 0: the bits order like the values
+        const double pv = proj(&W.rec[er], pt.x, pt.y, pt.z);
+        atomicMax(&W.top[er], (unsigned long long)__double_as_longlong(pv));   // pv >= 0: the bits order like the values
     }
     wave_sync();
     {
-        const double mytop = __longlong_as_double((long long)top_all[wave][row]);
+        const double mytop = __longlong_as_double((long long)W.top[row]);
         const bool sane = mytop > 1e-280 && mytop < 1e280;   // the shortcuts below assume a plain double
         to_redo(act && !sane);
         act = act && sane;
@@ -1233,8 +1236,8 @@ __global__ __launch_bounds__(FX_WAVE *NW, 3) void pca_sets_quad_kernel(PcaArgs A
     for (int e = lane; e < n_slow; e += FX_WAVE) {
         const float4 pt = list[e];
         const int er = __float_as_int(pt.w);
-        const QuadRec *rec = &rec_all[wave][er];
-        const double top = __longlong_as_double((long long)top_all[wave][er]);
+        const QuadRec *rec = &W.rec[er];
+        const double top = __longlong_as_double((long long)W.top[er]);
         if (!(top > 1e-280 && top < 1e280))
             continue;
         // step = top / n_bins, correctly rounded, from the host's correctly rounded 1 / n_bins (two residual
@@ -1258,6 +1261,47 @@ __global__ __launch_bounds__(FX_WAVE *NW, 3) void pca_sets_quad_kernel(PcaArgs A
                 h += hist[(row * QUAD_COPIES + c) * QUAD_PITCH + i];
             A.out[set * width + 9 + i] = (float)h / (float)n;
         }
+    }
+}
+
+
+// A wave per four sets of one list.
+template <int NW, int PPL>
+__global__ __launch_bounds__(FX_WAVE *NW, PPL <= 4 ? 5 : PPL <= 8 ? 4 : 3) void pca_sets_quad_kernel(PcaArgs A, double inv_nb)
+{
+    __shared__ QuadLds lds[NW];
+    const int64_t n_sets = A.n_sets_dev ? (int64_t)*A.n_sets_dev : A.n_sets;
+    const int64_t first = ((int64_t)blockIdx.x * NW + fx_wave()) * QUAD_SETS;
+    if (first >= n_sets)
+        return;   // the whole wave; there is no block barrier
+    pca_sets_quad_body<PPL>(A, lds[fx_wave()], n_sets, first, inv_nb);
+}
+
+// The three lists of small sets that the classification of a ragged batch builds (up to 256, 128 and 64 points,
+// lengths in counts[0..2]) in one launch: the waves of the grid are dealt to the lists in that order, four
+// entries each, so the launch has no more waves than one over a single list of all small sets would have (plus
+// one per list for its last, partly filled wave), and a set of 40 points costs a quarter of the point slots.
+struct QuadLists {
+    const int32_t *ids[3];
+    const int32_t *counts;
+};
+template <int NW>
+__global__ __launch_bounds__(FX_WAVE *NW, 3) void pca_sets_quad_mixed_kernel(PcaArgs A, QuadLists Q, double inv_nb)
+{
+    __shared__ QuadLds lds[NW];
+    const int wave = __builtin_amdgcn_readfirstlane(fx_wave());
+    const int64_t w = (int64_t)blockIdx.x * NW + wave;
+    const int c0 = Q.counts[0], c1 = Q.counts[1], c2 = Q.counts[2];
+    const int64_t w0 = (c0 + QUAD_SETS - 1) / QUAD_SETS, w1 = (c1 + QUAD_SETS - 1) / QUAD_SETS, w2 = (c2 + QUAD_SETS - 1) / QUAD_SETS;
+    if (w < w0) {
+        A.set_ids = Q.ids[0];
+        pca_sets_quad_body<16>(A, lds[wave], c0, w * QUAD_SETS, inv_nb);
+    } else if (w < w0 + w1) {
+        A.set_ids = Q.ids[1];
+        pca_sets_quad_body<8>(A, lds[wave], c1, (w - w0) * QUAD_SETS, inv_nb);
+    } else if (w < w0 + w1 + w2) {
+        A.set_ids = Q.ids[2];
+        pca_sets_quad_body<4>(A, lds[wave], c2, (w - w0 - w1) * QUAD_SETS, inv_nb);
     }
 }
 
@@ -1934,8 +1978,9 @@ int launch_ragged_sets(const PcaArgs &A, hipStream_t s)
     return FX_OK;
 }
 
-// Sets of up to QUAD_MAX_POINTS points, four per wave; A.redo_list / A.redo_count take the sets left over.
-int launch_quad_sets(const PcaArgs &A, hipStream_t s)
+// Sets of up to max_points <= QUAD_MAX_POINTS points, four per wave; A.redo_list / A.redo_count take the sets left
+// over.
+int launch_quad_sets(const PcaArgs &A, int64_t max_points, hipStream_t s)
 {
     constexpr int NW = FX_PCA_NW;
     const int64_t waves = (A.n_sets + QUAD_SETS - 1) / QUAD_SETS;
@@ -1944,7 +1989,28 @@ int launch_quad_sets(const PcaArgs &A, hipStream_t s)
     FX_REQUIRE(A.redo_list && A.redo_count, "fx_pca_batch_f32: no list for the sets to redo");
     if (!A.redo_zeroed)
         FX_HIP_CHECK(hipMemsetAsync(A.redo_count, 0, sizeof(int32_t), s));
-    hipLaunchKernelGGL((pca_sets_quad_kernel<NW>), dim3((unsigned)blocks), dim3(FX_WAVE * NW), 0, s, A, 1.0 / (double)A.n_bins);
+    auto k = max_points <= QUAD_LANES * 4 ? pca_sets_quad_kernel<NW, 4>
+             : max_points <= QUAD_LANES * 8 ? pca_sets_quad_kernel<NW, 8> : pca_sets_quad_kernel<NW, 16>;
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(FX_WAVE * NW), 0, s, A, 1.0 / (double)A.n_bins);
+    PcaArgs R = A;
+    R.set_ids = A.redo_list;
+    R.n_sets_dev = A.redo_count;
+    hipLaunchKernelGGL((pca_sets_redo_kernel<4, NW, true>), dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(FX_WAVE * NW), 0, s, R);
+    FX_HIP_CHECK(hipGetLastError());
+    return FX_OK;
+}
+
+// The three lists of small sets of a ragged batch (Q; at most n_sets entries together) in one launch.
+int launch_quad_lists(const PcaArgs &A, const QuadLists &Q, hipStream_t s)
+{
+    constexpr int NW = FX_PCA_NW;
+    const int64_t waves = (A.n_sets + QUAD_SETS - 1) / QUAD_SETS + 3;   // (a partly filled wave per list)
+    const int64_t blocks = (waves + NW - 1) / NW;
+    FX_REQUIRE(blocks <= 0x7fffffffLL, "fx_pca_batch_f32: too many sets for one launch");
+    FX_REQUIRE(A.redo_list && A.redo_count, "fx_pca_batch_f32: no list for the sets to redo");
+    if (!A.redo_zeroed)
+        FX_HIP_CHECK(hipMemsetAsync(A.redo_count, 0, sizeof(int32_t), s));
+    hipLaunchKernelGGL((pca_sets_quad_mixed_kernel<NW>), dim3((unsigned)blocks), dim3(FX_WAVE * NW), 0, s, A, Q, 1.0 / (double)A.n_bins);
     PcaArgs R = A;
     R.set_ids = A.redo_list;
     R.n_sets_dev = A.redo_count;
@@ -1956,7 +2022,7 @@ int launch_quad_sets(const PcaArgs &A, hipStream_t s)
 int launch_reg_sets(const PcaArgs &A, int64_t max_points, bool ragged, hipStream_t s)
 {
     if (max_points <= QUAD_MAX_POINTS)
-        return launch_quad_sets(A, s);
+        return launch_quad_sets(A, max_points, s);
     if (!ragged && !A.offsets && !A.set_ids) {
         if (max_points == 1024)
             return launch_full_sets<16>(A, s);
@@ -1987,11 +2053,12 @@ int launch_small_sets(const PcaArgs &A, int64_t max_points, hipStream_t s)
 // Work lists of a batch: the sets of a CSR batch sorted by the kernel that takes them (built on the device by
 // pca_classify_kernel), and for the large clouds the chunk lists.
 struct RaggedLists {
-    int32_t *counts;       // [0] register-path sets, [1] LDS-path sets, [2] large clouds, [3] chunks, [4] small sets;
+    int32_t *counts;       // [0] register-path sets, [1] LDS-path sets, [2] large clouds, [3] chunks, [4] - [6] small
+                           // sets (up to 256, 128, 64 points);
                            // [16] - [18] sets that the three set launches leave to their second kernel
     int32_t *reg_ids;      // [B]
     int32_t *lds_ids;      // [B]
-    int32_t *quad_ids;     // [B] sets of up to QUAD_MAX_POINTS points (four per wave)
+    int32_t *quad_ids[3];  // [B] each: sets of up to 256, 128 and 64 points (four per wave)
     int32_t *cloud_ids;    // [max_clouds]
     int32_t *cloud_first;  // [max_clouds + 1]
     CloudChunk *chunks;    // [max_chunks]
@@ -2011,10 +2078,12 @@ constexpr int CLASSIFY_THREADS = 1024, CLASSIFY_WAVES = CLASSIFY_THREADS / FX_WA
 __global__ __launch_bounds__(CLASSIFY_THREADS) void pca_classify_kernel(PcaArgs A, RaggedLists L, int64_t B, int64_t reg_max,
                                                                        int all_clouds)
 {
-    // one atomic per block and list (thousands of waves adding to the same four counters take turns at the L2);
-    // within a block the sets keep their order
-    __shared__ int wave_cnt[CLASSIFY_WAVES][4];
-    __shared__ int block_base[4];
+    // one atomic per block and list (thousands of waves adding to the same few counters take turns at the L2);
+    // within a block the sets keep their order.  Lists 0 - 2: register path, LDS path, large clouds; 3 - 5: small
+    // sets of up to 256, 128, 64 points.
+    constexpr int LISTS = 6;
+    __shared__ int wave_cnt[CLASSIFY_WAVES][LISTS];
+    __shared__ int block_base[LISTS];
     const int64_t b = (int64_t)blockIdx.x * CLASSIFY_THREADS + threadIdx.x;
     int cls = -1;
     bool bad = false;
@@ -2024,12 +2093,17 @@ __global__ __launch_bounds__(CLASSIFY_THREADS) void pca_classify_kernel(PcaArgs 
         const int64_t n = pca_set_size(A, b);
         bad = A.offsets && L.total > 0 && (A.offsets[b] < 0 || A.offsets[b + 1] > L.total);
         if (!bad)
-            cls = all_clouds ? 2 : n <= QUAD_MAX_POINTS ? 3 : n <= reg_max ? 0 : n <= WAVE_SET_MAX_POINTS ? 1 : 2;
+            cls = all_clouds ? 2
+                  : n <= QUAD_LANES * 4 ? 5
+                  : n <= QUAD_LANES * 8 ? 4
+                  : n <= QUAD_MAX_POINTS ? 3
+                  : n <= reg_max ? 0
+                  : n <= WAVE_SET_MAX_POINTS ? 1 : 2;
     }
     const int lane = fx_lane(), wave = fx_wave();
     unsigned long long mine = 0ull;   // the lanes of this wave in the same list as this lane
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
+    for (int c = 0; c < LISTS; c++) {
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(cls == c);
         if (lane == 0)
             wave_cnt[wave][c] = (int)__builtin_popcountll(mask);
@@ -2037,19 +2111,19 @@ __global__ __launch_bounds__(CLASSIFY_THREADS) void pca_classify_kernel(PcaArgs 
             mine = mask;
     }
     __syncthreads();
-    if (threadIdx.x < 4) {
+    if (threadIdx.x < LISTS) {
         const int c = threadIdx.x;
         int total = 0;
         for (int w = 0; w < CLASSIFY_WAVES; w++)
             total += wave_cnt[w][c];
-        block_base[c] = total ? atomicAdd(&L.counts[c == 3 ? 4 : c], total) : 0;
+        block_base[c] = total ? atomicAdd(&L.counts[c < 3 ? c : c + 1], total) : 0;
     }
     __syncthreads();
     if (cls >= 0) {
         int pos = block_base[cls] + (int)__builtin_popcountll(mine & ((1ull << lane) - 1ull));
         for (int w = 0; w < wave; w++)
             pos += wave_cnt[w][cls];
-        int32_t *list = cls == 0 ? L.reg_ids : cls == 1 ? L.lds_ids : cls == 2 ? L.cloud_ids : L.quad_ids;
+        int32_t *list = cls == 0 ? L.reg_ids : cls == 1 ? L.lds_ids : cls == 2 ? L.cloud_ids : L.quad_ids[cls - 3];
         const int64_t room = cls == 0 ? L.max_reg : cls == 1 ? L.max_lds : cls == 2 ? L.max_clouds : B;
         if (pos < room)
             list[pos] = (int32_t)b;
@@ -2263,14 +2337,15 @@ int launch_ragged_on_device(const PcaArgs &A, int64_t B, int64_t total, bool all
     RaggedLists L = {};
     CloudWork Wk = {};
     const size_t cloud_bytes = cloud_layout(nullptr, max_clouds, max_chunks, L, Wk);
-    unsigned char *base = (unsigned char *)guard.scratch(counts_bytes + 3 * ids_bytes + redo_bytes + cloud_bytes, 2);
+    unsigned char *base = (unsigned char *)guard.scratch(counts_bytes + 5 * ids_bytes + redo_bytes + cloud_bytes, 2);
     if (!base)
         return FX_ENOMEM;
     unsigned char *p = base;
     L.counts = (int32_t *)p, p += counts_bytes;
     L.reg_ids = (int32_t *)p, p += ids_bytes;
     L.lds_ids = (int32_t *)p, p += ids_bytes;
-    L.quad_ids = (int32_t *)p, p += ids_bytes;
+    for (int c = 0; c < 3; c++)
+        L.quad_ids[c] = (int32_t *)p, p += ids_bytes;
     int32_t *redo = (int32_t *)p;
     p += redo_bytes;
     cloud_layout(p, max_clouds, max_chunks, L, Wk);
@@ -2296,13 +2371,15 @@ int launch_ragged_on_device(const PcaArgs &A, int64_t B, int64_t total, bool all
     int rc = FX_OK;
     if (!all_clouds) {
         PcaArgs S = A;
-        S.set_ids = L.quad_ids;
-        S.n_sets = B;                 // sizes the grid; the kernel reads the true count
-        S.n_sets_dev = L.counts + 4;
+        S.n_sets = B;                 // sizes the grid; the kernel reads the true counts
         S.redo_count = L.counts + 16;   // (counts are zero; the launches run one after the other and share the list)
         S.redo_zeroed = 1;
         S.redo_list = redo + 64;
-        rc = launch_quad_sets(S, s);
+        QuadLists Q;
+        for (int c = 0; c < 3; c++)
+            Q.ids[c] = L.quad_ids[c];
+        Q.counts = L.counts + 4;
+        rc = launch_quad_lists(S, Q, s);
     }
     if (rc == FX_OK && !all_clouds) {
         PcaArgs S = A;

@@ -321,12 +321,15 @@ def test_ragged_batch_of_many_small_sets_and_bad_offsets(gpu, oracle):
 
 
 @pytest.mark.parametrize("N,dims,normalize,nb", [(3, 3, False, 8), (5, 3, True, 8), (16, 3, False, 4), (17, 2, False, 8),
-                                                 (100, 3, True, 16), (255, 3, False, 8), (256, 3, False, 8),
+                                                 (64, 3, False, 8), (64, 2, True, 8), (65, 3, False, 8),
+                                                 (100, 3, True, 16), (128, 3, True, 8), (129, 2, False, 8),
+                                                 (255, 3, False, 8), (256, 3, False, 8),
                                                  (256, 2, True, 8), (200, 3, False, 64)])
 def test_small_sets_four_per_wave(gpu, oracle, N, dims, normalize, nb):
     """Uniform batches of up to 256 points per set (four sets share a wave), including the sets that path hands
     on: identical points, collinear points, two tight clusters, a set far from the origin; 2-D sets are (x, y, 0).
-    The batch size leaves the last wave with one set."""
+    The batch size leaves the last wave with one set.  (The kernel keeps 4, 8 or 16 points per lane: sets of up to
+    64, 128, 256 points.)"""
     import torch
     eng = pkg("engine")
     rng = np.random.default_rng(1000 * N + dims)
@@ -360,6 +363,38 @@ def test_small_sets_four_per_wave(gpu, oracle, N, dims, normalize, nb):
             assert abs(got[7] - ref_out[7]) <= 2e-2 * abs(ref_out[7])
             got[7] = ref_out[7]
         ties += compare_set(got, eig[b], ref_out, ref_eig, N, strict_rel=not degenerate)
+    assert ties <= 3
+
+
+@pytest.mark.parametrize("dims", [3, 2])
+def test_ragged_small_sets_of_all_three_sizes_in_one_launch(gpu, oracle, dims):
+    """A CSR batch whose small sets fall into the three lists of the small-set launch (up to 64, 128, 256 points),
+    the sizes next to the limits among them, list lengths that are not multiples of four; every set against the
+    oracle."""
+    import torch
+    eng = pkg("engine")
+    rng = np.random.default_rng(31 + dims)
+    sizes = np.concatenate([[3, 4, 63, 64, 65, 127, 128, 129, 255, 256, 257, 0, 2], rng.integers(3, 300, size=150)])
+    rng.shuffle(sizes)
+    off = np.zeros(len(sizes) + 1, dtype=np.int64)
+    np.cumsum(sizes, out=off[1:])
+    pts = (rng.normal(size=(int(off[-1]), dims)) * np.array([1.0, 0.4, 0.1][:dims])).astype(np.float32)
+    res = eng.pca_batch(torch.from_numpy(pts).to(gpu), torch.from_numpy(off).to(gpu), 8, False, eig=True)
+    out, eig = res["out"].cpu().numpy(), res["eig"].cpu().numpy()
+    ties = 0
+    for b, n in enumerate(sizes):
+        if n < 3:
+            assert np.isnan(out[b]).all()
+            continue
+        p = np.zeros((n, 3), dtype=np.float64)
+        p[:, :dims] = pts[off[b]:off[b + 1]]
+        ref_out, ref_eig = oracle.compute_pca_features(p, 8, False, return_eig=True)
+        got = out[b].copy()
+        degenerate = ref_eig[2] <= 1e-9 * ref_eig[0]
+        if degenerate:   # (2-D sets, three points: lambda3 is rounding noise, and ratio23 shows it)
+            assert abs(got[7] - ref_out[7]) <= 2e-2 * abs(ref_out[7])
+            got[7] = ref_out[7]
+        ties += compare_set(got, eig[b], ref_out, ref_eig, int(n), strict_rel=not degenerate)
     assert ties <= 3
 
 

@@ -216,6 +216,24 @@ if __name__ == "__main__":
         for _ in range(5): eng.pca_batch(pts2, d_off)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5 * 1e3
         print(f"pca 2-D ragged B=200000 sizes 100..2048: {dt:.3f} ms per call  {off[-1]*8/dt/1e6:.0f} GB/s", flush=True)
+    elif what == "pcas":   # uniform batches of small sets
+        for (B, N) in [(1000000, 256), (1000000, 128), (1000000, 64), (1000000, 32), (2000000, 16)]:
+            ms, gbps = time_pca(B, N, reps=8)
+            print(f"pca B={B} N={N}: {ms:.3f} ms  {gbps:.0f} GB/s  {ms*1e6/B:.3f} ns/set", flush=True)
+    elif what == "pcaq":   # one ragged batch of small sets (for counter runs)
+        import numpy as np
+        rng = np.random.default_rng(0)
+        lo, hi, B = (int(v) for v in os.environ.get("PCAQ", "3,256,1000000").split(","))
+        sizes = rng.integers(lo, hi + 1, B)
+        off = np.zeros(B + 1, dtype=np.int64); np.cumsum(sizes, out=off[1:])
+        pts = torch.randn((int(off[-1]), 3), dtype=torch.float32, device=dev)
+        d_off = torch.from_numpy(off).to(dev)
+        for _ in range(2): eng.pca_batch(pts, d_off)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3): eng.pca_batch(pts, d_off)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3 * 1e3
+        print(f"pca ragged B={B} sizes {lo}..{hi}: {dt:.3f} ms per call  {off[-1]*12/dt/1e6:.0f} GB/s", flush=True)
     elif what == "sil1":
         ms, gbps = time_sil(20000, 224, 224, 224, reps=3)
         print(f"sil B=20000 224x224->224: {ms:.3f} ms  {gbps:.0f} GB/s", flush=True)
