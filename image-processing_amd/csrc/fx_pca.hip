@@ -2074,9 +2074,10 @@ __device__ __forceinline__ int64_t pca_set_size(const PcaArgs &A, int64_t set)
 }
 
 constexpr int CLASSIFY_THREADS = 1024, CLASSIFY_WAVES = CLASSIFY_THREADS / FX_WAVE;
-// all_clouds: every set goes to the cloud list (float64 input)
+// mode 1: every set goes to the cloud list (float64 input); mode 2: every set that is no large cloud goes to the
+// register list (batches of few sets, see launch_ragged_on_device)
 __global__ __launch_bounds__(CLASSIFY_THREADS) void pca_classify_kernel(PcaArgs A, RaggedLists L, int64_t B, int64_t reg_max,
-                                                                       int all_clouds)
+                                                                       int mode)
 {
     // one atomic per block and list (thousands of waves adding to the same few counters take turns at the L2);
     // within a block the sets keep their order.  Lists 0 - 2: register path, LDS path, large clouds; 3 - 5: small
@@ -2093,7 +2094,8 @@ __global__ __launch_bounds__(CLASSIFY_THREADS) void pca_classify_kernel(PcaArgs 
         const int64_t n = pca_set_size(A, b);
         bad = A.offsets && L.total > 0 && (A.offsets[b] < 0 || A.offsets[b + 1] > L.total);
         if (!bad)
-            cls = all_clouds ? 2
+            cls = mode == 1 ? 2
+                  : mode == 2 ? (n <= WAVE_SET_MAX_POINTS ? 0 : 2)
                   : n <= QUAD_LANES * 4 ? 5
                   : n <= QUAD_LANES * 8 ? 4
                   : n <= QUAD_MAX_POINTS ? 3
@@ -2317,6 +2319,9 @@ int launch_large_clouds(const PcaArgs &A, const int32_t *h_sets, const int64_t *
     return run_clouds<T>(A, L, Wk, s);
 }
 
+constexpr int64_t FEW_SETS = 2048;   // batches of up to this many sets take one launch for all their sets below the
+                                     // large clouds
+
 // Ragged batch without a host round trip: `total` is the caller's count of points behind d_pts (an upper bound
 // of offsets[B]), from which the sizes of the lists and of the per-chunk records are bounded.  all_clouds: every
 // set takes the cloud path (float64 input).
@@ -2359,16 +2364,34 @@ int launch_ragged_on_device(const PcaArgs &A, int64_t B, int64_t total, bool all
         return most < B ? (most > 1 ? most : 1) : B;
     };
     const int64_t reg_bound = bound(QUAD_MAX_POINTS), lds_bound = bound(REG_SET_MAX_POINTS);
-    L.max_reg = reg_bound;
+    // A batch of few sets (the tail configuration: some dozens of clouds) is not worth six launches for its sets
+    // of up to WAVE_SET_MAX_POINTS points -- a launch that finds its list empty still costs 9 us of the stream's
+    // time, as much as the sets themselves: they all go to one list and to the register kernel with 32 points per
+    // lane, which takes any size up to that limit.
+    const bool few = !all_clouds && B <= FEW_SETS;
+    L.max_reg = few ? B : reg_bound;
     L.max_lds = lds_bound;
 
     FX_HIP_CHECK(hipMemsetAsync(L.counts, 0, counts_bytes, s));
     const int64_t reg_max = REG_SET_MAX_POINTS;
     hipLaunchKernelGGL(pca_classify_kernel, dim3((unsigned)((B + CLASSIFY_THREADS - 1) / CLASSIFY_THREADS)), dim3(CLASSIFY_THREADS), 0, s, A, L, B,
-                       reg_max, all_clouds ? 1 : 0);
+                       reg_max, all_clouds ? 1 : few ? 2 : 0);
     FX_HIP_CHECK(hipGetLastError());
     FxProfileScope prof(s);
     int rc = FX_OK;
+    if (few) {
+        PcaArgs S = A;
+        S.set_ids = L.reg_ids;
+        S.n_sets = B;
+        S.n_sets_dev = L.counts + 0;
+        S.redo_count = L.counts + 16;
+        S.redo_zeroed = 1;
+        S.redo_list = redo + 64;
+        rc = launch_small_sets(S, WAVE_SET_MAX_POINTS, s);   // the register kernel with 32 points per lane
+        if (rc != FX_OK)
+            return rc;
+        return run_clouds<T>(A, L, Wk, s);
+    }
     if (!all_clouds) {
         PcaArgs S = A;
         S.n_sets = B;                 // sizes the grid; the kernel reads the true counts

@@ -185,13 +185,15 @@ def test_variable_size_clouds_tail_config(gpu, oracle, normalize):
     np.testing.assert_allclose(eig2.cpu().numpy()[:, :3], eig[:, :3], rtol=1e-12, atol=0)
 
 
-def test_point_count_smaller_than_the_offsets_say(gpu):
+@pytest.mark.parametrize("copies", [1, 400])
+def test_point_count_smaller_than_the_offsets_say(gpu, copies):
     """The caller's point count bounds what may be read: sets that reach beyond it get NaN rows, whichever
-    kernel their size would have sent them to; the sets inside it are computed as ever."""
+    kernel their size would have sent them to; the sets inside it are computed as ever.  (A batch of few sets
+    takes one launch for all its sets below the large clouds, a larger one a launch per size class: both.)"""
     import torch
     eng = pkg("engine")
     rng = np.random.default_rng(77)
-    sizes = [100, 5000, 300, 20000, 3, 1500]
+    sizes = [100, 5000, 300, 20000, 3, 1500] * copies
     off = np.zeros(len(sizes) + 1, dtype=np.int64)
     np.cumsum(sizes, out=off[1:])
     flat = torch.from_numpy(rng.normal(size=(int(off[-1]), 3)).astype(np.float32)).to(gpu)
@@ -199,7 +201,8 @@ def test_point_count_smaller_than_the_offsets_say(gpu):
     full = eng.pca_batch(flat, d_off, 8, False)["out"].cpu().numpy()
     assert np.isfinite(full).all()
     out = torch.zeros((len(sizes), 17), dtype=torch.float32, device=gpu)
-    for cut in (int(off[2]) + 10, int(off[3]) + 4096, int(off[1])):
+    first = len(sizes) - 6   # (the cuts fall into the last copy of the six sizes)
+    for cut in (int(off[first + 2]) + 10, int(off[first + 3]) + 4096, int(off[first + 1])):
         out.zero_()
         pkg("_lib").call("fx_pca_batch_f32", flat.data_ptr(), d_off.data_ptr(), len(sizes), cut, 3, 8, 0,
                          out.data_ptr(), 0, int(torch.cuda.current_stream().cuda_stream))
@@ -221,7 +224,7 @@ def test_offsets_that_overlap_cannot_overrun_a_list(gpu):
     rng = np.random.default_rng(5)
     flat = torch.from_numpy(rng.normal(size=(3000, 3)).astype(np.float32)).to(gpu)
     for n in (600, 1500, 2500):   # register list, LDS list, large clouds
-        B = 41
+        B = 4101   # (more sets than a batch that takes one launch for all its sets may have)
         off = np.zeros(B + 1, dtype=np.int64)
         off[1::2] = n                       # sets 0, 2, 4, ... are points 0 .. n; the odd ones run backwards
         d_off = torch.from_numpy(off).to(gpu)
@@ -374,7 +377,7 @@ def test_ragged_small_sets_of_all_three_sizes_in_one_launch(gpu, oracle, dims):
     import torch
     eng = pkg("engine")
     rng = np.random.default_rng(31 + dims)
-    sizes = np.concatenate([[3, 4, 63, 64, 65, 127, 128, 129, 255, 256, 257, 0, 2], rng.integers(3, 300, size=150)])
+    sizes = np.concatenate([[3, 4, 63, 64, 65, 127, 128, 129, 255, 256, 257, 0, 2], rng.integers(3, 300, size=2150)])
     rng.shuffle(sizes)
     off = np.zeros(len(sizes) + 1, dtype=np.int64)
     np.cumsum(sizes, out=off[1:])
