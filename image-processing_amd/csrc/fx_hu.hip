@@ -1223,17 +1223,18 @@ __global__ __launch_bounds__(FX_BLOCK) void hu_finalize_kernel(HuArgs A, BandScr
 // once to double (for images up to 512 x 512 this is the value OpenCV's
 // double accumulation holds exactly; beyond, it is the value that accumulation
 // approximates), then lane 0 finalises as usual.
-__global__ __launch_bounds__(FX_WAVE) void hu_tile_combine_kernel(HuArgs A, BandScratch G, int gray)
+__global__ __launch_bounds__(FX_BLOCK) void hu_tile_combine_kernel(HuArgs A, BandScratch G, int gray)
 {
     typedef unsigned __int128 u128;
+    __shared__ u64 wave_sums[FX_WAVES_PER_BLOCK][10][2];
     const int64_t b = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int lane = fx_lane(), wave = fx_wave();
     const int tiles = A.tiles_x * A.tiles_y;
     u128 M[10];
 #pragma unroll
     for (int k = 0; k < 10; k++)
         M[k] = 0;
-    for (int tile = lane; tile < tiles; tile += FX_WAVE) {
+    for (int tile = threadIdx.x; tile < tiles; tile += FX_BLOCK) {   // (the 128-bit products are the kernel's time)
         const u64 *t = G.sums + (b * tiles + tile) * BAND_SUMS;
         const int tyi = tile / A.tiles_x, txi = tile - tyi * A.tiles_x;
         const u128 X = (u128)(txi * TILE_W), Y = (u128)(tyi * TILE_H) + (u128)(A.partial ? A.y_offset : 0);
@@ -1261,8 +1262,23 @@ __global__ __launch_bounds__(FX_WAVE) void hu_tile_combine_kernel(HuArgs A, Band
             }
         }
     }
-    if (lane != 0)
+    // the waves' sums through LDS (integer sums: any order gives the same bits)
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 10; k++) {
+            wave_sums[wave][k][0] = (u64)M[k];
+            wave_sums[wave][k][1] = (u64)(M[k] >> 64);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x != 0)
         return;
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+        M[k] = 0;
+        for (int w = 0; w < FX_WAVES_PER_BLOCK; w++)
+            M[k] += ((u128)wave_sums[w][k][1] << 64) | wave_sums[w][k][0];
+    }
     const u128 scale = gray ? 1 : (u128)A.on_value;
     if (A.partial) {
         const u64 limb = (1ull << 48) - 1;
@@ -1523,7 +1539,7 @@ int hu_batch_impl(const char *who, const HuScratch &scratch, const uint8_t *d_im
         }
         if (rc != FX_OK)
             return rc;
-        hipLaunchKernelGGL(hu_tile_combine_kernel, dim3((unsigned)B), dim3(FX_WAVE), 0, s, A, G,
+        hipLaunchKernelGGL(hu_tile_combine_kernel, dim3((unsigned)B), dim3(FX_BLOCK), 0, s, A, G,
                            mode == MODE_GRAY ? 1 : 0);
         FX_HIP_CHECK(hipGetLastError());
         return FX_OK;
@@ -1708,7 +1724,7 @@ extern "C" int fx_hu_partial_u8(const uint8_t *d_img, int64_t B, int H, int W, i
     }
     if (rc != FX_OK)
         return rc;
-    hipLaunchKernelGGL(hu_tile_combine_kernel, dim3((unsigned)B), dim3(FX_WAVE), 0, s, A, G,
+    hipLaunchKernelGGL(hu_tile_combine_kernel, dim3((unsigned)B), dim3(FX_BLOCK), 0, s, A, G,
                        mode == MODE_GRAY ? 1 : 0);
     FX_HIP_CHECK(hipGetLastError());
     return FX_OK;
