@@ -9,7 +9,7 @@ a)  bash tools/round_bench.sh $rnd c3 c2 c4 c5 || exit 1
     for wl in c3 c4 c5; do bash tools/collect_profiles.sh $wl profiles/$rnd || exit 1; done ;;
 b)  bash tools/round_bench.sh $rnd f1 p1 || exit 1
     for wl in c2 f1 p1; do bash tools/collect_profiles.sh $wl profiles/$rnd || exit 1; done ;;
-c)  for k in c5 pcar husmall pca1m fps render; do
+c)  for k in c5 pcar pcas husmall pca1m fps render png; do
         timeout -k 10 240 python3 tools/kbench.py $k > gpurun_out/$rnd/kbench_$k.txt 2>&1 || exit 1
         tail -3 gpurun_out/$rnd/kbench_$k.txt
     done
