@@ -163,6 +163,37 @@ __device__ __forceinline__ void fx_eig3(double a00, double a01, double a02, doub
         v1[k] = (i0 == 0) ? V[k][0] : ((i0 == 1) ? V[k][1] : V[k][2]);
 }
 
+// First principal axis of the symmetric 2x2 matrix [[a00 a01][a01 a11]]: the operations fx_eig3 performs on
+// [[a00 a01 0][a01 a11 0][0 0 0]], in its order (one rotation, after which the matrix is diagonal; the
+// third coordinate never couples), without the sweep loop and the 3x3 bookkeeping, so the result has the
+// same bits.
+__device__ __forceinline__ void fx_eig2_axis(double a00, double a01, double a11, double &vx, double &vy)
+{
+    double c = 1.0, s = 0.0;
+    const double off = fabs(a01), diag = fabs(a00) + fabs(a11);
+    if (!(off == 0.0 || off <= 1e-19 * diag)) {
+        const double d = a11 - a00;
+        const double two = a01 + a01;
+        const double h = sqrt(d * d + two * two);
+        double t = two / (fabs(d) + h);
+        if (d < 0.0)
+            t = -t;
+        c = 1.0 / sqrt(t * t + 1.0);
+        s = t * c;
+        const double tap = t * a01;
+        a00 = a00 - tap;
+        a11 = a11 + tap;
+    }
+    // columns of the rotation: (c, -s) belongs to a00, (s, c) to a11; the zero eigenvalue of the third
+    // coordinate wins only over two negative ones
+    const bool second = a00 < a11;
+    const double w = second ? a11 : a00;
+    vx = second ? s : c;
+    vy = second ? c : -s;
+    if (w < 0.0)
+        vx = vy = 0.0;
+}
+
 // Direct solve for well-conditioned matrices (three clearly separated,
 // clearly positive eigenvalues -- what a cloud of points in general position
 // gives), a few hundred instructions without a loop over sweeps:

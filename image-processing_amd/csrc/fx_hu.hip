@@ -582,7 +582,7 @@ __device__ __forceinline__ void hu_image_body(const HuArgs &A, const int64_t b, 
 
     if (top > 0.0) {
         const double step = top / (double)nb;
-        const double inv_step = (double)nb / top;
+        const double inv_step = (double)nb * fx_rcp_n1(top);  // first guess of a bin only: fx_hist_bin settles it against `step`
         if (wactive) {
             for (int y = wy; y < H; y += WR) {
                 uint32_t bw = contour_word(mask, A.wpr, y, wx);
@@ -696,30 +696,47 @@ __device__ __forceinline__ void band_contour_hist(const HuArgs &A, const int64_t
     const uint32_t wcap = (uint32_t)(A.qcap >> 2);
     if (cnt[0] > wcap || cnt[1] > wcap || cnt[2] > wcap || cnt[3] > wcap)
         return;  // the mask kernel redoes the image
-    u64 cs[6];
-#pragma unroll
-    for (int k = 0; k < 6; k++)
-        cs[k] = red[10 + k] + red[BAND_SUMS + 10 + k] + red[2 * BAND_SUMS + 10 + k] + red[3 * BAND_SUMS + 10 + k];
-    const u64 n = cs[0];
+    const u64 n = red[10] + red[BAND_SUMS + 10] + red[2 * BAND_SUMS + 10] + red[3 * BAND_SUMS + 10];
     if (n < 3)
         return;  // hu_finalize_kernel writes the NaN row
-    // centroid and first principal axis exactly as hu_finalize_kernel derives
-    // them (every lane computes the same values: no broadcast, no barrier)
-    const double dn = (double)n;
-    const double inv = 1.0 / (dn * (double)(n - 1));
-    const i64 sx = (i64)cs[1], sy = (i64)cs[2];
-    const double cxx = (double)((i64)(n * cs[3]) - sx * sx) * inv;
-    const double cxy = (double)((i64)(n * cs[4]) - sx * sy) * inv;
-    const double cyy = (double)((i64)(n * cs[5]) - sy * sy) * inv;
-    double lam[3], v1[3];
-    fx_eig3(cxx, cxy, 0.0, cyy, 0.0, 0.0, lam, v1);
-    const double ccx = (double)sx / dn, ccy = (double)sy / dn, vx = v1[0], vy = v1[1];
-    const float cx32 = (float)ccx, cy32 = (float)ccy, vx32 = (float)vx, vy32 = (float)vy;
-
-    // the edge rows have been exchanged before the last barrier: their LDS holds the four histograms now
+#if defined(HX_CUT) && HX_CUT == 1
+    return;
+#endif
+    // Centroid and first principal axis as hu_finalize_kernel derives them.  The streaming loop leaves
+    // the vector ALU nearly full for small images, so the serial float64 part runs on one wave and the
+    // other three fetch its four results from LDS instead of repeating it.
     uint32_t *hist_all = reinterpret_cast<uint32_t *>(lds_raw + BAND_LDS_EDGES);
     uint32_t *hist = hist_all + wave * FX_WAVE;
+    // the edge rows have been exchanged before the last barrier: their LDS holds the four histograms now
     hist[lane] = 0;
+    if (wave == 0) {
+        u64 cs[6];
+        cs[0] = n;
+#pragma unroll
+        for (int k = 1; k < 6; k++)
+            cs[k] = red[10 + k] + red[BAND_SUMS + 10 + k] + red[2 * BAND_SUMS + 10 + k] + red[3 * BAND_SUMS + 10 + k];
+        const double dn = (double)n;
+        const double inv = 1.0 / (dn * (double)(n - 1));
+        const i64 sx = (i64)cs[1], sy = (i64)cs[2];
+        const double cxx = (double)((i64)(n * cs[3]) - sx * sx) * inv;
+        const double cxy = (double)((i64)(n * cs[4]) - sx * sy) * inv;
+        const double cyy = (double)((i64)(n * cs[5]) - sy * sy) * inv;
+        double ax, ay;
+        fx_eig2_axis(cxx, cxy, cyy, ax, ay);
+        if (lane == 0) {
+            bcast[4] = (double)sx / dn;
+            bcast[5] = (double)sy / dn;
+            bcast[6] = ax;
+            bcast[7] = ay;
+        }
+    }
+    __syncthreads();
+    const double ccx = bcast[4], ccy = bcast[5], vx = bcast[6], vy = bcast[7];
+    const float cx32 = (float)ccx, cy32 = (float)ccy, vx32 = (float)vx, vy32 = (float)vy;
+#if defined(HX_CUT) && HX_CUT == 2
+    if (t == 0) A.cpca[b * (9 + A.n_bins) + 9] = vx32 + vy32 + cx32 + cy32;
+    return;
+#endif
 
     auto sproj = [&](uint32_t X, int i, double dyv) -> double {
         return fma(dyv, vy, ((double)(int)(X + i) - ccx) * vx);
@@ -760,24 +777,11 @@ __device__ __forceinline__ void band_contour_hist(const HuArgs &A, const int64_t
     };
 
     // ---- largest |projection| ---------------------------------------------------
-    float top32 = 0.0f;
-    for (int i = lane; i < qn; i += FX_WAVE) {
-        float a, c;
-        ends32(wq[i], a, c);
-        top32 = fmaxf(top32, fmaxf(fabsf(a), fabsf(c)));
-    }
-    top32 = fx_wave_max_f32_dpp(top32);
-    // float32 error bound of a projection (coordinates below 1024, |v| <= 1): a few 1e-4; the factor is generous
-    const float eps_w = 4e-7f * (top32 + fabsf(cx32) + fabsf(cy32) + 1024.0f);
-    // the wave's exact maximum is among the few segments within the error bound of the float32 one
+    // both ends of every segment in float64 (a float32 pass that picks the candidates first costs more
+    // than it saves: the vector ALU runs float64 at the same rate)
     double top = 0.0;
-    for (int i = lane; i < qn; i += FX_WAVE) {
-        const uint32_t e = wq[i];
-        float a, c;
-        ends32(e, a, c);
-        if (fmaxf(fabsf(a), fabsf(c)) >= top32 - 2.0f * eps_w)
-            top = larger(e, top);
-    }
+    for (int i = lane; i < qn; i += FX_WAVE)
+        top = larger(wq[i], top);
     top = fx_wave_max_f64_dpp(top);
     if (lane == 0)
         bcast[wave] = top;
@@ -786,6 +790,10 @@ __device__ __forceinline__ void band_contour_hist(const HuArgs &A, const int64_t
 
     const int nb = A.n_bins;
     float *out = A.cpca + b * (9 + nb) + 9;
+#if defined(HX_CUT) && HX_CUT == 3
+    if (t == 0) out[0] = (float)top;
+    return;
+#endif
     if (!(top > 0.0)) {
         if (t < nb)
             out[t] = t == 0 ? 1.0f : 0.0f;
@@ -793,7 +801,7 @@ __device__ __forceinline__ void band_contour_hist(const HuArgs &A, const int64_t
     }
     // ---- histogram ----------------------------------------------------------------
     const double step = top / (double)nb;
-    const double inv_step = (double)nb / top;
+    const double inv_step = (double)nb * fx_rcp_n1(top);  // first guess of a bin only: fx_hist_bin settles it against `step`
     const float eps = 4e-7f * ((float)top * 1.000001f + fabsf(cx32) + fabsf(cy32) + 1024.0f);
     // float32 bin of |s|, or -1 when |s| / step is within `margin` of an integer
     const float inv32 = (float)inv_step;
@@ -822,6 +830,9 @@ __device__ __forceinline__ void band_contour_hist(const HuArgs &A, const int64_t
         defer(e != 0u && !whole, e);
     }
     list_ready();
+#if defined(HX_CUT) && HX_CUT == 4
+    nl = 0;
+#endif
     // one pixel at a time: float32 where it is certain, float64 otherwise
     for (uint32_t i = lane; i < nl; i += FX_WAVE) {
         const uint32_t e = list[i];

@@ -140,6 +140,11 @@ if __name__ == "__main__":
             ms, gbps = time_hu(B,H,W,c)
             print(f"hu B={B} {H}x{W} contour={c}: {ms:.3f} ms  {gbps:.0f} GB/s", flush=True)
             torch.cuda.empty_cache()
+    elif what == "hutail":   # the contour variant's block tail at the reference's view sizes
+        for (B,H,W,c) in [(200000,224,224,True),(100000,256,256,True),(60000,512,512,True)]:
+            ms, gbps = time_hu(B,H,W,c)
+            print(f"hu B={B} {H}x{W} contour={c}: {ms:.3f} ms  {gbps:.0f} GB/s", flush=True)
+            torch.cuda.empty_cache()
     elif what == "hulds":
         for (B,H,W,c) in [(60000,512,512,True),(60000,512,512,False),(100000,256,256,True)]:
             ms, gbps = time_hu(B,H,W,c)
