@@ -146,38 +146,69 @@ constexpr BandTab make_band_tab()
 __device__ const BandTab g_band_tab = make_band_tab();
 constexpr int BAND_TAB_BYTES = (int)sizeof(BandTab);  // 4 KiB
 
+// acc += a * b for a, b below 2^24: one full-rate instruction.  (Written as C, hipcc proves the factors
+// small, drops the 24-bit multiply for a plain one and emits v_mul_lo_u32, which issues at a quarter of
+// the rate, plus an add.)  Only for factors that ordinary VALU instructions produced: hipcc does not
+// see into the string, so it inserts none of the wait states a v_dot4 result would need.
+__device__ __forceinline__ void mad24(uint32_t &acc, uint32_t a, uint32_t b)
+{
+    asm("v_mad_u32_u24 %0, %1, %2, %0" : "+v"(acc) : "s"(a), "v"(b));
+}
+
 // TAB: the moment sums of a 0/1-weighted chunk come from two lookups in `tab`
-// (an LDS copy of g_band_tab) instead of twenty dot products.
+// (an LDS copy of g_band_tab at a fixed offset) instead of twenty dot products.
 template <int MODE, bool TAB = false>
 __device__ __forceinline__ void chunk_sums(const uint4 &v, uint32_t kthr, uint32_t j, Acc32 &a,
-                                           uint32_t &bits16, const BandTabEntry *tab = nullptr)
+                                           uint32_t &bits16, const unsigned char *tab = nullptr)
 {
     uint32_t w[4] = {v.x, v.y, v.z, v.w};
     uint32_t src[4];
-    uint32_t fg[4];  // 0/1 per byte: foreground of the contour mask
+    uint32_t fg[4];  // foreground of the contour mask: 0/1 per byte, or 0/128 (SH = 7)
+    // pixel > 127 is bit 7 of the byte: with 0/1 weights the bit stays where it is and the mask
+    // comes out of the dot products times 128
+    constexpr int SH = (MODE == MODE_BIT7 && TAB) ? 7 : 0;
 #pragma unroll
     for (int d = 0; d < 4; d++) {
         if (MODE == MODE_THRESH) {
             fg[d] = gt_bytes(w[d], kthr);
             src[d] = fg[d];
+        } else if (SH) {
+            fg[d] = w[d] & 0x80808080u;
+            src[d] = 0;  // the table supplies the sums
         } else {
             fg[d] = (w[d] >> 7) & 0x01010101u;
             src[d] = (MODE == MODE_BIT7) ? fg[d] : w[d];
         }
     }
     // byte k of a dword weighs 2^k (low nibble) or 2^(k+4): the dot products are the mask bits
-    const uint32_t lo8 = dot4(fg[1], 0x80402010u, dot4(fg[0], 0x08040201u, 0u));
-    const uint32_t hi8 = dot4(fg[3], 0x80402010u, dot4(fg[2], 0x08040201u, 0u));
-    bits16 = lo8 | (hi8 << 8);
+    const uint32_t lo8 = dot4(fg[1], 0x80402010u, dot4(fg[0], 0x08040201u, 0u));  // << SH
+    const uint32_t hi8 = dot4(fg[3], 0x80402010u, dot4(fg[2], 0x08040201u, 0u));  // << SH
+    bits16 = SH ? ((lo8 >> SH) | (hi8 << (8 - SH))) : (lo8 | (hi8 << 8));
 
     uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
     if (TAB && MODE != MODE_GRAY) {
-        const BandTabEntry L = tab[lo8], U = tab[256 + hi8];
+        static_assert(sizeof(BandTabEntry) == 8, "table entries are addressed as mask * 8");
+        const uint32_t ol = SH > 3 ? lo8 >> (SH - 3) : lo8 << (3 - SH);
+        const uint32_t oh = SH > 3 ? hi8 >> (SH - 3) : hi8 << (3 - SH);
+        const uint2 L = *reinterpret_cast<const uint2 *>(tab + ol);
+        const uint2 U = *reinterpret_cast<const uint2 *>(tab + 256 * sizeof(BandTabEntry) + oh);
         const uint32_t packed = L.x + U.x;
         s0 = packed & 31u;
         s1 = (packed >> 5) & 127u;
         s2 = packed >> 12;
         s3 = L.y + U.y;
+        const uint32_t j2 = j * j, j3 = j2 * j;  // j < 128, wave-uniform
+        a.a00 += s0;
+        a.a10 += s1;
+        a.a20 += s2;
+        a.a30 += s3;
+        mad24(a.a01, j, s0);
+        mad24(a.a11, j, s1);
+        mad24(a.a21, j, s2);
+        mad24(a.a02, j2, s0);
+        mad24(a.a12, j2, s1);
+        mad24(a.a03, j3, s0);
+        return;
     } else {
         uint32_t s3l = 0, s3h = 0;
 #pragma unroll
@@ -636,16 +667,19 @@ __global__ __launch_bounds__(FX_BLOCK) void hu_image_kernel(HuArgs A)
 // code that would idle 255 of 256 threads inside the streaming kernel).
 constexpr int BAND_LDS_COUNTERS = LDS_HEAD_BYTES;          // 16 B: segments queued by each wave
 constexpr int BAND_LDS_EDGES = BAND_LDS_COUNTERS + 16;     // top/bottom row masks of every band; later 4 x 64 histogram counters
-// per-wave region: the wave's part of the segment queue (contour variant) or
-// the 4 KiB slab of the wave-level reduction (moments only); the contour
-// variant has its slabs, later the lists of undecided segments, behind the
-// lookup table
-constexpr int BAND_LDS_WAVE = BAND_LDS_EDGES + 4 * FX_BLOCK;
+// the lookup table of the 0/1-weighted modes at a fixed offset (the lookups then address it with an
+// immediate), behind it the four reduction slabs of the contour variant, then the per-wave regions:
+// the wave's part of the segment queue (contour variant) or the 4 KiB slab of the wave-level
+// reduction (moments only)
+constexpr int BAND_LDS_TAB = BAND_LDS_EDGES + 4 * FX_BLOCK;
 constexpr int BAND_SLAB_BYTES = 4096;
 #ifndef BAND_VPP_CONTOUR
 #define BAND_VPP_CONTOUR 4
 #endif
 constexpr int BAND_CSLAB_BYTES = BAND_VPP_CONTOUR * FX_WAVE * 8;  // slab of the contour variant
+constexpr int BAND_LDS_CSLAB = BAND_LDS_TAB + BAND_TAB_BYTES;
+constexpr int band_lds_wave(bool contour) { return BAND_LDS_CSLAB + (contour ? FX_WAVES_PER_BLOCK * BAND_CSLAB_BYTES : 0); }
+constexpr int BAND_LDS_FIXED = BAND_LDS_CSLAB;  // bytes in front of the slabs and the per-wave regions
 constexpr int TILE_W = 1024, TILE_H = 256;                 // tiled mode: one block per tile, 64 rows per wave
 constexpr int BAND_SUMS = 16;                              // u64 per image: 10 raw moments + 6 contour sums
 
@@ -861,7 +895,9 @@ __device__ __forceinline__ void band_contour_hist(const HuArgs &A, const int64_t
 #ifndef FX_BAND_WAVES
 #define FX_BAND_WAVES 4
 #endif
-template <int MODE, bool CONTOUR, bool ALIGNED>
+// ALIGNED: 0 rows are read byte by byte; 1 and 2 every chunk is a whole, 16-byte aligned vector, read with
+// a global load (1) or a buffer load (2).
+template <int MODE, bool CONTOUR, int ALIGNED>
 __global__ __launch_bounds__(FX_BLOCK, FX_BAND_WAVES) void hu_band_kernel(HuArgs A, BandScratch G)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -888,9 +924,9 @@ __global__ __launch_bounds__(FX_BLOCK, FX_BAND_WAVES) void hu_band_kernel(HuArgs
 
     // 0/1 weights: the moment sums of a chunk are looked up by its mask bytes
     constexpr bool TAB = MODE != MODE_GRAY;
-    const BandTabEntry *tab = reinterpret_cast<const BandTabEntry *>(lds_raw + BAND_LDS_WAVE + FX_WAVES_PER_BLOCK * wave_bytes);
+    const unsigned char *tab = lds_raw + BAND_LDS_TAB;
     if (TAB) {
-        uint2 *dst = reinterpret_cast<uint2 *>(lds_raw + BAND_LDS_WAVE + FX_WAVES_PER_BLOCK * wave_bytes);
+        uint2 *dst = reinterpret_cast<uint2 *>(lds_raw + BAND_LDS_TAB);
         const uint2 *srct = reinterpret_cast<const uint2 *>(g_band_tab.e);
         dst[t] = srct[t];
         dst[t + FX_BLOCK] = srct[t + FX_BLOCK];
@@ -904,14 +940,33 @@ __global__ __launch_bounds__(FX_BLOCK, FX_BAND_WAVES) void hu_band_kernel(HuArgs
     const int ya = band * hb;
     const uint32_t kthr = (uint32_t)(255 - (A.thresh < 0 ? 127 : A.thresh)) * 0x00010001u;
 
-    // ALIGNED: every chunk is a whole, 16-byte aligned vector.  The load is then
-    // unconditional (rows outside the band or the image read a clamped address
-    // and are zeroed afterwards), which lets the four loads of a group issue
-    // back to back.
+    // ALIGNED == 2: buffer loads.  The descriptor of a row (scalar registers, built by the scalar unit)
+    // starts at the row's offset in the image or tile and ends where the image ends; a lane adds the
+    // offset of its band's first row and its chunk.  Rows below the image, lanes without a chunk and
+    // rows past the band (no records) come back as zeros from the range check: no address arithmetic,
+    // no compare and no select on the vector unit, which the small images (bands of a few rows, the
+    // vector unit nearly full) are bound by: 224 x 224 +8 %.  Bands of 64 rows and more stream 1-2 %
+    // faster with global loads (ALIGNED == 1: rows outside the band or the image read a clamped address
+    // and are zeroed afterwards); either way the four loads of a group issue back to back.
+    typedef uint32_t band_u32x4 __attribute__((ext_vector_type(4)));
+    const uint32_t pitch32 = (uint32_t)A.pitch;
+    const uint32_t span = (uint32_t)(H - 1) * pitch32 + (uint32_t)W;  // bytes of the image (tile) from its first pixel
+    const uint32_t voff = active ? (uint32_t)ya * pitch32 + (uint32_t)x0 : 0x7FFFFFFFu;
     auto load_chunk = [&](int r) -> uint4 {
+        if (ALIGNED == 2) {
+            const uint32_t roff = (uint32_t)r * pitch32;
+            // signed and through max(): an unsigned saturating subtraction exists only on the vector
+            // unit, and a descriptor word in a vector register wraps every load in a loop over lanes
+            const int left = max((int)span - (int)roff, 0);
+            const int records = __builtin_amdgcn_readfirstlane(r < hb ? left : 0);
+            const __amdgpu_buffer_rsrc_t rsrc =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(img) + roff, 0, records, 0x00020000);
+            const band_u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 2 /* nt */);
+            return make_uint4(q.x, q.y, q.z, q.w);
+        }
         const int y = ya + r;
         const bool valid = active && r < hb && y < H;
-        if (ALIGNED) {
+        if (ALIGNED == 1) {
             const int yc = valid ? y : 0;
             const int xc = active ? x0 : 0;
             uint4 v = fx_load_once16(img + (int64_t)yc * A.pitch + xc);
@@ -939,7 +994,7 @@ __global__ __launch_bounds__(FX_BLOCK, FX_BAND_WAVES) void hu_band_kernel(HuArgs
     // comes from a ballot, so no atomic is needed.  A segment is the 16-pixel
     // mask | (row << 6 | chunk) << 16.
     const int wcap = A.qcap >> 2;
-    uint32_t *wq = reinterpret_cast<uint32_t *>(lds_raw + BAND_LDS_WAVE + wave * wave_bytes);
+    uint32_t *wq = reinterpret_cast<uint32_t *>(lds_raw + band_lds_wave(CONTOUR) + wave * wave_bytes);
     uint32_t wn = 0;  // wave-uniform: segments this wave has queued (may run past wcap: overflow)
     auto push = [&](int r, uint32_t bits) {
         const unsigned long long m = __ballot(bits != 0);
@@ -1131,8 +1186,8 @@ __global__ __launch_bounds__(FX_BLOCK, FX_BAND_WAVES) void hu_band_kernel(HuArgs
     // [value][lane]; lane l then adds VPP adjacent lanes of one value and a few
     // butterfly steps finish the 64-lane sum.  (With VPP = 8: 16 LDS accesses
     // and 6 cross-lane moves per lane instead of 12 cross-lane moves per value.)
-    unsigned char *slab_raw = CONTOUR ? lds_raw + BAND_LDS_WAVE + FX_WAVES_PER_BLOCK * wave_bytes + BAND_TAB_BYTES + wave * BAND_CSLAB_BYTES
-                                      : lds_raw + BAND_LDS_WAVE + wave * wave_bytes;
+    unsigned char *slab_raw = CONTOUR ? lds_raw + BAND_LDS_CSLAB + wave * BAND_CSLAB_BYTES
+                                      : lds_raw + band_lds_wave(false) + wave * wave_bytes;
     u64 *slab = reinterpret_cast<u64 *>(slab_raw);
     // contour variant: 4 values per pass in a 2 KiB slab (LDS per block decides how many blocks a CU holds)
     constexpr int VPP = CONTOUR ? BAND_VPP_CONTOUR : 8;
@@ -1174,7 +1229,7 @@ __global__ __launch_bounds__(FX_BLOCK, FX_BAND_WAVES) void hu_band_kernel(HuArgs
         G.sums[b * BAND_SUMS + t] = sum;
     }
     if (CONTOUR)
-        band_contour_hist(A, b, lds_raw, reinterpret_cast<uint32_t *>(lds_raw + BAND_LDS_WAVE + wave * wave_bytes), qn);
+        band_contour_hist(A, b, lds_raw, wq, qn);
 }
 
 // One lane per image: everything that is serial float64 arithmetic.
@@ -1375,20 +1430,32 @@ int launch_image_kernel(const HuArgs &A, bool aligned, size_t lds, hipStream_t s
     return FX_OK;
 }
 
+// How the band kernel reads the rows (its ALIGNED parameter).  The buffer loads address a row as a
+// 32-bit offset from the image's (tile's) first pixel; they pay for bands of fewer than 64 rows.
+inline int band_aligned(bool aligned, int W, int H, int64_t pitch_bytes, int hb)
+{
+    if (!aligned || W % 16 != 0)
+        return 0;
+    const int64_t rows = (H < 1024 ? H : 1024) + 512;  // a block sees a tile or an image of at most 1024 rows; bands may start below it
+    return hb < 64 && rows * pitch_bytes < (1ll << 31) ? 2 : 1;
+}
+
 template <int MODE, bool CONTOUR>
-int launch_band_kernel(const HuArgs &A, const BandScratch &G, bool aligned, size_t lds, hipStream_t s)
+int launch_band_kernel(const HuArgs &A, const BandScratch &G, int aligned, size_t lds, hipStream_t s)
 {
     const int64_t blocks = A.tiles_x > 0 ? A.B * A.tiles_x * A.tiles_y : A.B;
     dim3 grid((unsigned)blocks), block(FX_BLOCK);
-    if (aligned)
-        hipLaunchKernelGGL((hu_band_kernel<MODE, CONTOUR, true>), grid, block, lds, s, A, G);
+    if (aligned == 2)
+        hipLaunchKernelGGL((hu_band_kernel<MODE, CONTOUR, 2>), grid, block, lds, s, A, G);
+    else if (aligned == 1)
+        hipLaunchKernelGGL((hu_band_kernel<MODE, CONTOUR, 1>), grid, block, lds, s, A, G);
     else
-        hipLaunchKernelGGL((hu_band_kernel<MODE, CONTOUR, false>), grid, block, lds, s, A, G);
+        hipLaunchKernelGGL((hu_band_kernel<MODE, CONTOUR, 0>), grid, block, lds, s, A, G);
     FX_HIP_CHECK(hipGetLastError());
     return FX_OK;
 }
 
-int launch_band(const HuArgs &A, const BandScratch &G, int mode, bool contour, bool aligned, size_t lds, hipStream_t s)
+int launch_band(const HuArgs &A, const BandScratch &G, int mode, bool contour, int aligned, size_t lds, hipStream_t s)
 {
     if (contour)
         return mode == MODE_GRAY   ? launch_band_kernel<MODE_GRAY, true>(A, G, aligned, lds, s)
@@ -1546,7 +1613,7 @@ int hu_batch_impl(const char *who, const HuScratch &scratch, const uint8_t *d_im
         int rc;
         {
             FxProfileScope prof(s);
-            rc = launch_band(A, G, mode, false, aligned && (W % 16 == 0), (size_t)BAND_LDS_WAVE + (size_t)FX_WAVES_PER_BLOCK * A.wave_lds + BAND_TAB_BYTES, s);
+            rc = launch_band(A, G, mode, false, band_aligned(aligned, W, H, pitch_bytes, A.hb), (size_t)BAND_LDS_FIXED + (size_t)FX_WAVES_PER_BLOCK * A.wave_lds, s);
         }
         if (rc != FX_OK)
             return rc;
@@ -1580,8 +1647,7 @@ int hu_batch_impl(const char *who, const HuScratch &scratch, const uint8_t *d_im
         FX_HIP_CHECK(hipMemsetAsync(G.redo_count, 0, 16, s));
 
     A.wave_lds = contour && A.qcap > BAND_SLAB_BYTES ? A.qcap : BAND_SLAB_BYTES;  // qcap / 4 entries of 4 bytes
-    size_t band_lds = (size_t)BAND_LDS_WAVE + (size_t)FX_WAVES_PER_BLOCK * A.wave_lds + BAND_TAB_BYTES +
-                            (contour ? FX_WAVES_PER_BLOCK * BAND_CSLAB_BYTES : 0);
+    size_t band_lds = (size_t)band_lds_wave(contour) + (size_t)FX_WAVES_PER_BLOCK * A.wave_lds;
     // Blocks per CU follow from the LDS a block asks for: 31 KiB lets five in.  Bands of 64 rows and more
     // stream long enough that four blocks per CU keep the memory system busy, and measure 2 % faster than
     // five (fewer concurrent streams); shorter bands want the fifth block to cover the histogram tails.
@@ -1591,7 +1657,7 @@ int hu_batch_impl(const char *who, const HuScratch &scratch, const uint8_t *d_im
     int rc;
     {
         FxProfileScope prof(s);
-        rc = launch_band(A, G, mode, contour, aligned && (W % 16 == 0), band_lds, s);
+        rc = launch_band(A, G, mode, contour, band_aligned(aligned, W, H, pitch_bytes, A.hb), band_lds, s);
     }
     if (rc != FX_OK)
         return rc;
@@ -1730,8 +1796,8 @@ extern "C" int fx_hu_partial_u8(const uint8_t *d_img, int64_t B, int H, int W, i
     int rc;
     {
         FxProfileScope prof(s);
-        rc = launch_band(A, G, mode, false, aligned && (W % 16 == 0),
-                         (size_t)BAND_LDS_WAVE + (size_t)FX_WAVES_PER_BLOCK * A.wave_lds + BAND_TAB_BYTES, s);
+        rc = launch_band(A, G, mode, false, band_aligned(aligned, W, H, pitch_bytes, A.hb),
+                         (size_t)BAND_LDS_FIXED + (size_t)FX_WAVES_PER_BLOCK * A.wave_lds, s);
     }
     if (rc != FX_OK)
         return rc;

@@ -141,7 +141,16 @@ if __name__ == "__main__":
             print(f"hu B={B} {H}x{W} contour={c}: {ms:.3f} ms  {gbps:.0f} GB/s", flush=True)
             torch.cuda.empty_cache()
     elif what == "hutail":   # the contour variant's block tail at the reference's view sizes
-        for (B,H,W,c) in [(200000,224,224,True),(100000,256,256,True),(60000,512,512,True)]:
+        for (B,H,W,c) in [(200000,224,224,True),(100000,256,256,True),(125000,512,512,True)]:
+            ms, gbps = time_hu(B,H,W,c)
+            print(f"hu B={B} {H}x{W} contour={c}: {ms:.3f} ms  {gbps:.0f} GB/s", flush=True)
+            torch.cuda.empty_cache()
+    elif what == "hu1":   # one case from the environment, for counter passes: HU1="B,H,W,contour"
+        B,H,W,c = [int(x) for x in os.environ.get("HU1", "200000,224,224,1").split(",")]
+        ms, gbps = time_hu(B,H,W,bool(c),reps=2)
+        print(f"hu B={B} {H}x{W} contour={bool(c)}: {ms:.3f} ms  {gbps:.0f} GB/s", flush=True)
+    elif what == "hunc":   # moments only, from views to the tiled path
+        for (B,H,W,c) in [(200000,224,224,False),(100000,256,256,False),(125000,512,512,False),(8000,1024,1024,False),(64,8192,8192,False)]:
             ms, gbps = time_hu(B,H,W,c)
             print(f"hu B={B} {H}x{W} contour={c}: {ms:.3f} ms  {gbps:.0f} GB/s", flush=True)
             torch.cuda.empty_cache()
