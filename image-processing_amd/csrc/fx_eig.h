@@ -50,6 +50,22 @@ __device__ __forceinline__ double fx_rcp_n1(double x)
     const double r = __builtin_amdgcn_rcp(x);
     return fma(r, fma(-x, r, 1.0), r);
 }
+// Two Newton steps: the reciprocal to within an ulp, as the hardware division sequence forms it.
+__device__ __forceinline__ double fx_rcp_n2(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(r, fma(-x, r, 1.0), r);
+    return fma(r, fma(-x, r, 1.0), r);
+}
+// n / d from r = fx_rcp_n2(d): quotient estimate, exact residual, one correction -- the steps of the
+// compiler's IEEE division without the scaling and the fix-up that only denormal, infinite or zero
+// operands need.  Correctly rounded for ordinary operands; in particular exact whenever n / d is
+// representable.
+__device__ __forceinline__ double fx_div_r(double n, double d, double r)
+{
+    const double q = n * r;
+    return fma(fma(-d, q, n), r, q);
+}
 __device__ __forceinline__ double fx_rsq_n1(double x)
 {
     const double r = __builtin_amdgcn_rsq(x);
@@ -163,10 +179,10 @@ __device__ __forceinline__ void fx_eig3(double a00, double a01, double a02, doub
         v1[k] = (i0 == 0) ? V[k][0] : ((i0 == 1) ? V[k][1] : V[k][2]);
 }
 
-// First principal axis of the symmetric 2x2 matrix [[a00 a01][a01 a11]]: the operations fx_eig3 performs on
-// [[a00 a01 0][a01 a11 0][0 0 0]], in its order (one rotation, after which the matrix is diagonal; the
-// third coordinate never couples), without the sweep loop and the 3x3 bookkeeping, so the result has the
-// same bits.
+// First principal axis of the symmetric 2x2 matrix [[a00 a01][a01 a11]]: the one Jacobi rotation that
+// diagonalises it (what fx_eig3 does to [[a00 a01 0][a01 a11 0][0 0 0]]: the third coordinate never
+// couples), with the reciprocals from the hardware estimates plus a Newton step -- the axis is good to
+// a few ulp, as far from LAPACK's as LAPACK's is from the exact one.
 __device__ __forceinline__ void fx_eig2_axis(double a00, double a01, double a11, double &vx, double &vy)
 {
     double c = 1.0, s = 0.0;
@@ -174,11 +190,12 @@ __device__ __forceinline__ void fx_eig2_axis(double a00, double a01, double a11,
     if (!(off == 0.0 || off <= 1e-19 * diag)) {
         const double d = a11 - a00;
         const double two = a01 + a01;
-        const double h = sqrt(d * d + two * two);
-        double t = two / (fabs(d) + h);
+        const double h2 = fma(d, d, two * two);
+        const double h = h2 * fx_rsq_n1(h2);
+        double t = two * fx_rcp_n1(fabs(d) + h);
         if (d < 0.0)
             t = -t;
-        c = 1.0 / sqrt(t * t + 1.0);
+        c = fx_rsq_n1(fma(t, t, 1.0));
         s = t * c;
         const double tap = t * a01;
         a00 = a00 - tap;

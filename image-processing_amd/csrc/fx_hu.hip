@@ -733,9 +733,6 @@ __device__ __forceinline__ void band_contour_hist(const HuArgs &A, const int64_t
     const u64 n = red[10] + red[BAND_SUMS + 10] + red[2 * BAND_SUMS + 10] + red[3 * BAND_SUMS + 10];
     if (n < 3)
         return;  // hu_finalize_kernel writes the NaN row
-#if defined(HX_CUT) && HX_CUT == 1
-    return;
-#endif
     // Centroid and first principal axis as hu_finalize_kernel derives them.  The streaming loop leaves
     // the vector ALU nearly full for small images, so the serial float64 part runs on one wave and the
     // other three fetch its four results from LDS instead of repeating it.
@@ -750,16 +747,20 @@ __device__ __forceinline__ void band_contour_hist(const HuArgs &A, const int64_t
         for (int k = 1; k < 6; k++)
             cs[k] = red[10 + k] + red[BAND_SUMS + 10 + k] + red[2 * BAND_SUMS + 10 + k] + red[3 * BAND_SUMS + 10 + k];
         const double dn = (double)n;
-        const double inv = 1.0 / (dn * (double)(n - 1));
+        // the common factor of the covariance does not turn its axes: a reciprocal good to an ulp or two will do
+        const double inv = fx_rcp_n1(dn * (double)(n - 1));
         const i64 sx = (i64)cs[1], sy = (i64)cs[2];
         const double cxx = (double)((i64)(n * cs[3]) - sx * sx) * inv;
         const double cxy = (double)((i64)(n * cs[4]) - sx * sy) * inv;
         const double cyy = (double)((i64)(n * cs[5]) - sy * sy) * inv;
         double ax, ay;
         fx_eig2_axis(cxx, cxy, cyy, ax, ay);
+        // the centroid is the correctly rounded quotient (NumPy's mean of integer coordinates): pixels of
+        // symmetric shapes sit exactly on bin edges, and there the last bit of the centroid decides
+        const double rn = fx_rcp_n2(dn);
         if (lane == 0) {
-            bcast[4] = (double)sx / dn;
-            bcast[5] = (double)sy / dn;
+            bcast[4] = fx_div_r((double)sx, dn, rn);
+            bcast[5] = fx_div_r((double)sy, dn, rn);
             bcast[6] = ax;
             bcast[7] = ay;
         }
@@ -767,10 +768,6 @@ __device__ __forceinline__ void band_contour_hist(const HuArgs &A, const int64_t
     __syncthreads();
     const double ccx = bcast[4], ccy = bcast[5], vx = bcast[6], vy = bcast[7];
     const float cx32 = (float)ccx, cy32 = (float)ccy, vx32 = (float)vx, vy32 = (float)vy;
-#if defined(HX_CUT) && HX_CUT == 2
-    if (t == 0) A.cpca[b * (9 + A.n_bins) + 9] = vx32 + vy32 + cx32 + cy32;
-    return;
-#endif
 
     auto sproj = [&](uint32_t X, int i, double dyv) -> double {
         return fma(dyv, vy, ((double)(int)(X + i) - ccx) * vx);
@@ -816,6 +813,8 @@ __device__ __forceinline__ void band_contour_hist(const HuArgs &A, const int64_t
     double top = 0.0;
     for (int i = lane; i < qn; i += FX_WAVE)
         top = larger(wq[i], top);
+    // (one LDS atomic maximum per lane instead of the cross-lane steps and the exchange: 256 atomics on one
+    // address take four times as long as this whole pass)
     top = fx_wave_max_f64_dpp(top);
     if (lane == 0)
         bcast[wave] = top;
@@ -824,10 +823,6 @@ __device__ __forceinline__ void band_contour_hist(const HuArgs &A, const int64_t
 
     const int nb = A.n_bins;
     float *out = A.cpca + b * (9 + nb) + 9;
-#if defined(HX_CUT) && HX_CUT == 3
-    if (t == 0) out[0] = (float)top;
-    return;
-#endif
     if (!(top > 0.0)) {
         if (t < nb)
             out[t] = t == 0 ? 1.0f : 0.0f;
@@ -848,25 +843,44 @@ __device__ __forceinline__ void band_contour_hist(const HuArgs &A, const int64_t
             return -1;
         return (int)f;
     };
+    // A segment whose ends lie in adjacent bins on one side of zero: |projection| rises by |vx| per pixel
+    // from the end in the lower bin, so it reaches the edge between the two bins at the distance
+    // z = (edge - q0) / (|vx| / step) from that end, and the pixels nearer than z are below the edge.
+    // When a pixel's distance is within float32's reach of z (m2) the segment goes to the list.
+    const float adq = fabsf(vx32) * inv32;  // bins per pixel along a row
+    const float inv_adq = adq > 1e-4f ? __builtin_amdgcn_rcpf(adq) : 0.0f;  // 0: rows nearly perpendicular to the axis are not split this way
+    const float m2 = margin * inv_adq + 1e-5f;
     for (int base = 0; base < qn; base += FX_WAVE) {
         const int i = base + lane;
         const uint32_t e = i < qn ? wq[i] : 0u;
-        bool whole = false;
+        bool settled = false;
         if (e) {
+            const uint32_t bits = e & 0xFFFFu;
             float a, c;
             ends32(e, a, c);
             const int ba = bin32(a), bc = bin32(c);
             const bool same_side = (a > eps && c > eps) || (a < -eps && c < -eps);
-            whole = ba >= 0 && ba == bc && same_side;
-            if (whole)
-                atomicAdd(&hist[ba], (uint32_t)__popc(e & 0xFFFFu));
+            const bool sure = ba >= 0 && bc >= 0 && same_side;
+            const bool up = bc > ba;  // |projection| grows with x
+            const int b0 = up ? ba : bc, b1 = up ? bc : ba;
+            const int lo = __ffs((int)bits) - 1, hi = 31 - __clz((int)bits);
+            const float z = ((float)b1 - fabsf(up ? a : c) * inv32) * inv_adq;
+            const float zf = floorf(z);
+            const float fz = z - zf;
+            const int below = min(max((int)zf + 1, 0), hi - lo + 1);  // pixels at distances 0 .. floor(z) from the lower end
+            const uint32_t near_mask = up ? (1u << (lo + below)) - 1u : ~((1u << (hi + 1 - below)) - 1u);
+            const uint32_t all = (uint32_t)__popc(bits);
+            const uint32_t cum = b1 == b0 ? all : (uint32_t)__popc(bits & near_mask);
+            settled = sure && (b1 == b0 || (b1 == b0 + 1 && fz >= m2 && fz <= 1.0f - m2 && inv_adq > 0.0f));
+            if (settled) {
+                atomicAdd(&hist[b0], cum);
+                if (cum != all)
+                    atomicAdd(&hist[b1], all - cum);
+            }
         }
-        defer(e != 0u && !whole, e);
+        defer(e != 0u && !settled, e);
     }
     list_ready();
-#if defined(HX_CUT) && HX_CUT == 4
-    nl = 0;
-#endif
     // one pixel at a time: float32 where it is certain, float64 otherwise
     for (uint32_t i = lane; i < nl; i += FX_WAVE) {
         const uint32_t e = list[i];

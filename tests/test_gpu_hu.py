@@ -146,6 +146,36 @@ def test_contour_descriptor(gpu, oracle, size, nb):
     assert ties <= 2
 
 
+@pytest.mark.parametrize("size,nb", [((224, 224), 8), ((256, 256), 13), ((96, 200), 4), ((512, 512), 32)])
+def test_contour_histogram_of_symmetric_shapes(gpu, oracle, size, nb):
+    """Centred rectangles, ellipses and diamonds: the centroid is a half pixel, the axis lies along the grid,
+    rows of contour pixels cross bin edges and pixels sit exactly on them.  The kernel splits such rows at the
+    edge in closed form and takes the centroid from its own division sequence; both must agree with NumPy's
+    float64 result."""
+    H, W = size
+    yy, xx = np.mgrid[0:H, 0:W]
+    cy, cx = (H - 1) / 2, (W - 1) / 2
+    imgs = np.zeros((9, H, W), np.uint8)
+    for k in range(9):
+        ry, rx = H * (0.15 + 0.03 * k), W * (0.2 + 0.02 * k)
+        if k % 3 == 0:
+            imgs[k][(np.abs(yy - cy) <= ry) & (np.abs(xx - cx) <= rx)] = 255
+        elif k % 3 == 1:
+            imgs[k][((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0] = 255
+        else:
+            imgs[k][np.abs(yy - cy) / ry + np.abs(xx - cx) / rx <= 1.0] = 255
+    got = run_gpu(gpu, imgs, contour_bins=nb)
+    ties = 0
+    for b in range(imgs.shape[0]):
+        ref = oracle.contour_pca_features(imgs[b], 127, nb)
+        n = oracle.contour_points(imgs[b]).shape[0]
+        np.testing.assert_allclose(got["cpca"][b, :9], ref[:9], rtol=1e-6, atol=1e-30)
+        dcount = np.abs(got["cpca"][b, 9:].astype(np.float64) - ref[9:]) * n
+        ties += int(np.round(dcount.sum() / 2))
+        assert dcount.max() <= 2.5, "histogram differs by more than edge ties"
+    assert ties <= 2
+
+
 @pytest.mark.parametrize("size,B", [((2048, 2048), 2), ((1100, 1030), 3), ((3000, 4100), 2), ((8192, 8192), 1), ((1025, 16), 2)])
 def test_large_images_tiled_path(gpu, c_oracle, size, B):
     """Images beyond 1024 x 1024 are cut into tiles whose integer sums are
