@@ -2139,10 +2139,8 @@ __global__ __launch_bounds__(CLASSIFY_THREADS) void pca_classify_kernel(PcaArgs 
 // One block.  Exclusive prefix of the clouds' chunk counts -> cloud_first, total -> counts[3]; clouds of fewer
 // than three points, and clouds behind the point at which the chunk list would overflow (offsets that overlap),
 // get no chunks (pca_chunk_fill_kernel writes their NaN rows).
-__global__ __launch_bounds__(1024) void pca_cloud_scan_kernel(PcaArgs A, RaggedLists L)
+__device__ __forceinline__ void pca_cloud_scan_body(const PcaArgs &A, const RaggedLists &L, long long *wave_tot, int &carry_s, int &valid_s)
 {
-    __shared__ long long wave_tot[16];
-    __shared__ int carry_s, valid_s;
     const int t = threadIdx.x, lane = fx_lane(), wave = fx_wave();
     int n_clouds = L.counts[2];
     n_clouds = n_clouds < L.max_clouds ? n_clouds : (int)L.max_clouds;
@@ -2193,14 +2191,20 @@ __global__ __launch_bounds__(1024) void pca_cloud_scan_kernel(PcaArgs A, RaggedL
         L.counts[2] = n_clouds;
     }
 }
+__global__ __launch_bounds__(1024) void pca_cloud_scan_kernel(PcaArgs A, RaggedLists L)
+{
+    __shared__ long long wave_tot[16];
+    __shared__ int carry_s, valid_s;
+    pca_cloud_scan_body(A, L, wave_tot, carry_s, valid_s);
+}
 
 // A wave per cloud: its chunks' descriptors, its control record cleared; a cloud without chunks gets
 // its NaN row here.
-__global__ __launch_bounds__(FX_BLOCK) void pca_chunk_fill_kernel(PcaArgs A, RaggedLists L)
+__device__ __forceinline__ void pca_chunk_fill_body(const PcaArgs &A, const RaggedLists &L, int first_wave, int n_waves)
 {
     const int n_clouds = L.counts[2];
     const int lane = fx_lane();
-    for (int i = blockIdx.x * FX_WAVES_PER_BLOCK + fx_wave(); i < n_clouds; i += gridDim.x * FX_WAVES_PER_BLOCK) {
+    for (int i = first_wave; i < n_clouds; i += n_waves) {
         const int a = L.cloud_first[i], b = L.cloud_first[i + 1];
         if (a == b) {
             write_nan_row(A, L.cloud_ids[i], lane, FX_WAVE);
@@ -2221,6 +2225,80 @@ __global__ __launch_bounds__(FX_BLOCK) void pca_chunk_fill_kernel(PcaArgs A, Rag
         for (int k = lane; k < (int)(sizeof(CloudCtl) / sizeof(u64)); k += FX_WAVE)
             z[k] = 0ull;
     }
+}
+__global__ __launch_bounds__(FX_BLOCK) void pca_chunk_fill_kernel(PcaArgs A, RaggedLists L)
+{
+    pca_chunk_fill_body(A, L, blockIdx.x * FX_WAVES_PER_BLOCK + fx_wave(), gridDim.x * FX_WAVES_PER_BLOCK);
+}
+
+// Batches of few sets (up to FEW_SETS): one block does what memset, pca_classify_kernel (mode 2),
+// pca_cloud_scan_kernel and pca_chunk_fill_kernel do for large batches -- four launches of 4 - 5 us each on a
+// stream whose whole call takes 0.2 ms.  The steps read what the step before wrote to global memory: all of it
+// by this one block, between block barriers.
+__global__ __launch_bounds__(1024) void pca_few_prepare_kernel(PcaArgs A, RaggedLists L, int64_t B, int n_counts)
+{
+    __shared__ long long wave_tot[16];
+    __shared__ int carry_s, valid_s;
+    __shared__ int n_reg_s, n_cloud_s;
+    const int t = threadIdx.x;
+    for (int k = t; k < n_counts; k += 1024)
+        L.counts[k] = 0;
+    if (t == 0)
+        n_reg_s = 0, n_cloud_s = 0;
+    __syncthreads();
+    // sets in order within each list, as the classification kernel leaves them
+    for (int64_t b0 = 0; b0 < B; b0 += 1024) {
+        const int64_t b = b0 + t;
+        int cls = -1;
+        bool bad = false;
+        if (b < B) {
+            const int64_t n = pca_set_size(A, b);
+            bad = A.offsets && L.total > 0 && (A.offsets[b] < 0 || A.offsets[b + 1] > L.total);
+            if (!bad)
+                cls = n <= WAVE_SET_MAX_POINTS ? 0 : 2;
+        }
+        const unsigned long long m_reg = __builtin_amdgcn_ballot_w64(cls == 0), m_cloud = __builtin_amdgcn_ballot_w64(cls == 2);
+        const int wave = fx_wave(), lane = fx_lane();
+        if (lane == 0) {
+            wave_tot[wave] = (long long)__builtin_popcountll(m_reg) | ((long long)__builtin_popcountll(m_cloud) << 32);
+        }
+        __syncthreads();
+        if (cls >= 0) {
+            int pos = cls == 0 ? n_reg_s : n_cloud_s;
+            for (int w = 0; w < wave; w++)
+                pos += cls == 0 ? (int)(wave_tot[w] & 0xffffffffll) : (int)(wave_tot[w] >> 32);
+            pos += (int)__builtin_popcountll((cls == 0 ? m_reg : m_cloud) & ((1ull << lane) - 1ull));
+            int32_t *list = cls == 0 ? L.reg_ids : L.cloud_ids;
+            const int64_t room = cls == 0 ? L.max_reg : L.max_clouds;
+            if (pos < room)
+                list[pos] = (int32_t)b;
+            else
+                bad = true;   // more sets of this size than the point count allows: the offsets overlap
+        }
+        if (bad)
+            write_nan_row(A, b, 0, 1);
+        __syncthreads();
+        if (t == 0) {
+            int r = 0, c = 0;
+            for (int w = 0; w < 16; w++)
+                r += (int)(wave_tot[w] & 0xffffffffll), c += (int)(wave_tot[w] >> 32);
+            n_reg_s += r, n_cloud_s += c;
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        L.counts[0] = n_reg_s;
+        L.counts[2] = n_cloud_s;
+        carry_s = 0, valid_s = 0;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (L.max_clouds == 0 || L.max_chunks == 0)
+        return;
+    pca_cloud_scan_body(A, L, wave_tot, carry_s, valid_s);
+    __threadfence_block();
+    __syncthreads();
+    pca_chunk_fill_body(A, L, fx_wave(), 16);
 }
 
 __global__ __launch_bounds__(FX_BLOCK) void pca_iota_kernel(int32_t *ids, int64_t n)
@@ -2258,15 +2336,18 @@ size_t cloud_layout(unsigned char *base, int64_t max_clouds, int64_t max_chunks,
 }
 
 // Enqueues everything behind the cloud list: L.cloud_ids[0 .. counts[2]) hold the clouds (device memory).
+// prepared: pca_few_prepare_kernel has built the chunk list already.
 template <typename T>
-int run_clouds(const PcaArgs &A, RaggedLists &L, CloudWork &Wk, hipStream_t s)
+int run_clouds(const PcaArgs &A, RaggedLists &L, CloudWork &Wk, hipStream_t s, bool prepared = false)
 {
     const int64_t max_clouds = L.max_clouds, max_chunks = L.max_chunks;
     if (max_clouds == 0 || max_chunks == 0)
         return FX_OK;
-    hipLaunchKernelGGL(pca_cloud_scan_kernel, dim3(1), dim3(1024), 0, s, A, L);
-    hipLaunchKernelGGL(pca_chunk_fill_kernel, dim3((unsigned)(max_clouds < 4096 ? (max_clouds + FX_WAVES_PER_BLOCK - 1) / FX_WAVES_PER_BLOCK : 1024)),
-                       dim3(FX_BLOCK), 0, s, A, L);
+    if (!prepared) {
+        hipLaunchKernelGGL(pca_cloud_scan_kernel, dim3(1), dim3(1024), 0, s, A, L);
+        hipLaunchKernelGGL(pca_chunk_fill_kernel, dim3((unsigned)(max_clouds < 4096 ? (max_clouds + FX_WAVES_PER_BLOCK - 1) / FX_WAVES_PER_BLOCK : 1024)),
+                           dim3(FX_BLOCK), 0, s, A, L);
+    }
     const dim3 cgrid((unsigned)(max_chunks < 4096 ? max_chunks : 4096)), block(CLOUD_THREADS);
     const dim3 sgrid((unsigned)(max_clouds < 1024 ? max_clouds : 1024));
     int back = 1;   // (the passes over the points alternate in direction)
@@ -2372,10 +2453,14 @@ int launch_ragged_on_device(const PcaArgs &A, int64_t B, int64_t total, bool all
     L.max_reg = few ? B : reg_bound;
     L.max_lds = lds_bound;
 
-    FX_HIP_CHECK(hipMemsetAsync(L.counts, 0, counts_bytes, s));
     const int64_t reg_max = REG_SET_MAX_POINTS;
-    hipLaunchKernelGGL(pca_classify_kernel, dim3((unsigned)((B + CLASSIFY_THREADS - 1) / CLASSIFY_THREADS)), dim3(CLASSIFY_THREADS), 0, s, A, L, B,
-                       reg_max, all_clouds ? 1 : few ? 2 : 0);
+    if (few) {
+        hipLaunchKernelGGL(pca_few_prepare_kernel, dim3(1), dim3(1024), 0, s, A, L, B, (int)(counts_bytes / sizeof(int32_t)));
+    } else {
+        FX_HIP_CHECK(hipMemsetAsync(L.counts, 0, counts_bytes, s));
+        hipLaunchKernelGGL(pca_classify_kernel, dim3((unsigned)((B + CLASSIFY_THREADS - 1) / CLASSIFY_THREADS)), dim3(CLASSIFY_THREADS), 0, s, A, L, B,
+                           reg_max, all_clouds ? 1 : 0);
+    }
     FX_HIP_CHECK(hipGetLastError());
     FxProfileScope prof(s);
     int rc = FX_OK;
@@ -2390,7 +2475,7 @@ int launch_ragged_on_device(const PcaArgs &A, int64_t B, int64_t total, bool all
         rc = launch_small_sets(S, WAVE_SET_MAX_POINTS, s);   // the register kernel with 32 points per lane
         if (rc != FX_OK)
             return rc;
-        return run_clouds<T>(A, L, Wk, s);
+        return run_clouds<T>(A, L, Wk, s, true);
     }
     if (!all_clouds) {
         PcaArgs S = A;
