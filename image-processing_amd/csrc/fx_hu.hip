@@ -251,6 +251,24 @@ __device__ __forceinline__ void flush(const Acc32 &a, u64 y0, u64 R, Tot64 &t)
     t.t03 += y02 * y0 * a.a00 + 3 * y02 * R * a.a01 + 3 * y0 * R2 * a.a02 + R2 * R * a.a03;
 }
 
+// The same for the band kernel (every row visited, y0 < 2^14): the factors are given as 32-bit values, so
+// that a product is one v_mad_u64_u32 instead of the four multiplications of a 64 x 64-bit product.
+__device__ __forceinline__ void flush_band(const Acc32 &a, uint32_t y0, Tot64 &t)
+{
+    const u64 y1 = y0, y2 = (u64)(y0 * y0), y2x3 = (u64)(3u * y0 * y0), y1x2 = (u64)(2u * y0), y1x3 = (u64)(3u * y0);
+    const u64 y3 = y2 * y1;   // < 2^42
+    t.t00 += a.a00;
+    t.t10 += a.a10;
+    t.t20 += a.a20;
+    t.t30 += a.a30;
+    t.t01 += y1 * (u64)a.a00 + a.a01;
+    t.t11 += y1 * (u64)a.a10 + a.a11;
+    t.t21 += y1 * (u64)a.a20 + a.a21;
+    t.t02 += y2 * (u64)a.a00 + y1x2 * (u64)a.a01 + a.a02;
+    t.t12 += y2 * (u64)a.a10 + y1x2 * (u64)a.a11 + a.a12;
+    t.t03 += y3 * (u64)a.a00 + y2x3 * (u64)a.a01 + y1x3 * (u64)a.a02 + a.a03;
+}
+
 // Sum NV 64-bit values over the block; every thread gets the totals.  red is
 // LDS with room for FX_WAVES_PER_BLOCK * NV u64.
 template <int NV>
@@ -1015,9 +1033,12 @@ __global__ __launch_bounds__(FX_BLOCK, FX_BAND_WAVES) void hu_band_kernel(HuArgs
         if (m) {
             const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
             const uint32_t idx = wn + below;
-            if (bits && idx < (uint32_t)wcap)
+            const uint32_t after = wn + (uint32_t)__popcll(m);
+            // the room is checked for the wave as a whole (scalar): a wave that runs out of it stores
+            // nothing more, and its count past the limit sends the image to the mask kernel
+            if (after <= (uint32_t)wcap && bits)
                 wq[idx] = bits | ((uint32_t)(((ya + r) << 6) | tx) << 16);
-            wn += (uint32_t)__popcll(m);
+            wn = after;
         }
     };
     const bool has_left = tx > 0, has_right = tx < cpr - 1;
@@ -1111,13 +1132,13 @@ __global__ __launch_bounds__(FX_BLOCK, FX_BAND_WAVES) void hu_band_kernel(HuArgs
         Acc32 a;
         a.clear();
         run_rows(0, a);
-        flush(a, (u64)ya, 1ull, T);
+        flush_band(a, (uint32_t)ya, T);
     } else {
         for (int jb = 0; jb < hb; jb += SUB) {
             Acc32 a;
             a.clear();
             run_rows(jb, a);
-            flush(a, (u64)(ya + jb), 1ull, T);
+            flush_band(a, (uint32_t)(ya + jb), T);
         }
     }
 
@@ -1125,15 +1146,18 @@ __global__ __launch_bounds__(FX_BLOCK, FX_BAND_WAVES) void hu_band_kernel(HuArgs
     u64 V[NV];
     int qn = 0;  // segments in this wave's part of the queue
     {
-        const u64 X = (u64)x0, X2 = X * X, X3 = X2 * X;
+        // x0 <= 1008: every factor of the shift fits 32 bits (a 64 x 32-bit product is three multiplications
+        // instead of four, and the compiler cannot see that x0 is not negative)
+        const uint32_t xs = (uint32_t)x0;
+        const u64 X = xs, X2 = xs * xs, X3 = xs * xs * xs, Xx2 = 2u * xs, Xx3 = 3u * xs, X2x3 = 3u * xs * xs;
         V[0] = T.t00;
         V[1] = X * T.t00 + T.t10;
         V[2] = T.t01;
-        V[3] = X2 * T.t00 + 2 * X * T.t10 + T.t20;
+        V[3] = X2 * T.t00 + Xx2 * T.t10 + T.t20;
         V[4] = X * T.t01 + T.t11;
         V[5] = T.t02;
-        V[6] = X3 * T.t00 + 3 * X2 * T.t10 + 3 * X * T.t20 + T.t30;
-        V[7] = X2 * T.t01 + 2 * X * T.t11 + T.t21;
+        V[6] = X3 * T.t00 + X2x3 * T.t10 + Xx3 * T.t20 + T.t30;
+        V[7] = X2 * T.t01 + Xx2 * T.t11 + T.t21;
         V[8] = X * T.t02 + T.t12;
         V[9] = T.t03;
     }
