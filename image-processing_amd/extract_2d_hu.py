@@ -31,7 +31,7 @@ from pathlib import Path
 from typing import Any, Dict, Iterable, List, Optional, Sequence, Tuple
 
 import numpy as np
-from PIL import Image
+from PIL import Image, ImageOps
 
 logger = logging.getLogger("extract_2d_hu")
 
@@ -225,6 +225,116 @@ def append_to_csv(records: List[Dict[str, Any]], out_csv_path: Path, overwrite: 
         except Exception as e:
             logger.debug(f"Failed to append to existing CSV; will overwrite. Error: {e}")
     df_new.to_csv(out_csv_path, index=False)
+
+
+def _fit_panel(im, resolution: int, bg_rgb, resample):
+    """`im` as an RGB panel of resolution x resolution."""
+    if im.size != (resolution, resolution):
+        im = im.resize((resolution, resolution), resample=resample)
+    return im.convert("RGB")
+
+
+def save_preview(id: str, chosen_view_paths: List[Path], preproc_img: np.ndarray, mask: np.ndarray,
+                 out_preview_path: Path, bg_color: str, resolution: int) -> None:
+    """The three-part collage of a sample (reference :510-596): up to three raw views, each fitted into a
+    resolution x resolution square on the background colour, then the preprocessed image (bicubic if it has
+    another size), then the silhouette (nearest neighbour, re-thresholded at 128), side by side as one RGB PNG.
+    A part that cannot be produced is a blank square."""
+    bg_rgb = (255, 255, 255) if bg_color == "white" else (0, 0, 0)
+    side = (resolution, resolution)
+
+    def blank():
+        return Image.new("RGB", side, color=bg_rgb)
+
+    panels = []
+    for path in chosen_view_paths[:3]:
+        try:
+            thumb = ImageOps.contain(Image.open(path).convert("RGB"), side)
+            square = blank()
+            square.paste(thumb, ((resolution - thumb.width) // 2, (resolution - thumb.height) // 2))
+            panels.append(square)
+        except Exception:
+            panels.append(blank())
+    if not panels:
+        panels.append(blank())
+    try:
+        panels.append(_fit_panel(Image.fromarray(preproc_img).convert("L"), resolution, bg_rgb, Image.BICUBIC))
+    except Exception:
+        panels.append(blank())
+    try:
+        sil = Image.fromarray(mask).convert("L")
+        if sil.size != side:
+            sil = sil.resize(side, resample=Image.NEAREST)
+        panels.append(sil.point(lambda v: 255 if v > 128 else 0).convert("L").convert("RGB"))
+    except Exception:
+        panels.append(blank())
+    # every panel is resolution high, so the row needs no vertical padding
+    collage = Image.new("RGB", (sum(im.width for im in panels), resolution), color=bg_rgb)
+    x = 0
+    for im in panels:
+        collage.paste(im, (x, 0))
+        x += im.width
+    ensure_dir(out_preview_path.parent)
+    collage.save(str(out_preview_path), format="PNG")
+
+
+def write_previews(results: List[Dict[str, Any]], views_dir: Path, reports_dir: Path, n_preview: int, resolution: int,
+                   crop_margin: float, bg_color: str, preprocess_crop: bool, use_silhouette: bool,
+                   backend: Optional[str] = None) -> int:
+    """Collages of the first n_preview successful samples under reports_dir/sample_images (reference
+    :827-866): views 01, 05 and 09 (else the first three PNG files) on the left, then the preprocessed first of
+    them and its silhouette (the preprocessed image again without --use_silhouette).  The first views of all
+    previews go through the device in one batch per view size.  Prints the silhouette's white-pixel count for
+    the first five (the reference also prints the count of the Otsu mask before the component filter, an
+    intermediate the device does not write out).  Returns the number of collages written."""
+    import torch
+    from . import engine
+
+    picks = []
+    for r in [r for r in results if r.get("success")][:max(0, n_preview)]:
+        d = views_dir / r["id"]
+        chosen = [d / n for n in ("view_01.png", "view_05.png", "view_09.png") if (d / n).exists()]
+        if len(chosen) < 3:
+            chosen = sorted(d.glob("*.png"))[:3]
+        if chosen:
+            picks.append((r["id"], d, chosen))
+    groups: Dict[tuple, List[int]] = {}
+    first: List[Optional[np.ndarray]] = []
+    for k, (sid, d, chosen) in enumerate(picks):
+        try:
+            first.append(load_image(chosen[0]))
+            groups.setdefault(first[-1].shape, []).append(k)
+        except Exception as e:
+            first.append(None)
+            _log_error(reports_dir, d, "preview_failed", e)
+    done: Dict[int, tuple] = {}
+    fill = 255 if bg_color == "white" else 0
+    for shape, ks in groups.items():
+        try:
+            dev = torch.from_numpy(np.stack([first[k] for k in ks])).to(_device())
+            sil = engine.silhouette_batch(dev, resolution, crop_margin, preprocess_crop, info=True,
+                                          backend=backend or SILHOUETTE_BACKEND)
+            pre = engine.gray_fit_batch(dev, sil["info"], resolution, fill).cpu().numpy()
+            masks = sil["mask"].cpu().numpy()
+            for j, k in enumerate(ks):
+                done[k] = (pre[j], masks[j])
+        except Exception as e:
+            for k in ks:
+                _log_error(reports_dir, picks[k][1], "preview_failed", e)
+    written = 0
+    for k, (sid, d, chosen) in enumerate(picks):
+        if k not in done:
+            continue
+        pre, mask = done[k]
+        try:
+            save_preview(sid, chosen, pre, mask if use_silhouette else pre,
+                         reports_dir / "sample_images" / f"{sid}_hu_preview.png", bg_color, resolution)
+            written += 1
+            if written <= 5:
+                print(f"[mask-clean] {sid}: white-pixels after={int(np.count_nonzero(mask))}")
+        except Exception as e:
+            _log_error(reports_dir, d, "preview_failed", e)
+    return written
 
 
 def _log_error(reports_dir: Path, where, kind: str, msg) -> None:
@@ -491,7 +601,7 @@ def parse_args(argv=None):
     p.add_argument("--preprocess_crop", action="store_true")
     p.add_argument("--crop_margin", type=float, default=0.05)
     p.add_argument("--bg_color", type=str, default="white", choices=["white", "black"])
-    p.add_argument("--n_preview", type=int, default=0, help="accepted for compatibility; previews are not rendered")
+    p.add_argument("--n_preview", type=int, default=0, help="collages of the first N samples under reports_dir/sample_images")
     p.add_argument("--workers", type=int, default=None,
                    help="decode threads on the host (default: the cores, at most 16)")
     p.add_argument("--fast", action="store_true")
@@ -555,6 +665,9 @@ def main(argv=None) -> int:
             yaml.safe_dump(cfg, fh)
     except Exception:
         logger.debug("Failed to write config YAML")
+    if args.n_preview > 0:
+        write_previews(results, views_dir, reports_dir, int(args.n_preview), int(args.resolution), float(args.crop_margin),
+                       args.bg_color, bool(args.preprocess_crop), bool(args.use_silhouette), config["silhouette_backend"])
     mode = "fast" if args.fast else "full"
     print(f"Hu extraction finished. Mode: {mode}. Samples processed: {len(results)}. Descriptors saved to {out_dir}.")
     return 0

@@ -252,3 +252,35 @@ def test_clouds_to_hu_table_on_the_device(gpu, oracle, c_oracle, tmp_path):
     rec = hu.process_sample_worker(("tree_a", str(tmp_path / "views" / "tree_a"), cfg))
     direct = hu.hu_from_clouds(clouds[:1], views, res)
     np.testing.assert_array_equal(np.asarray(rec["vec"], dtype=np.float32), direct[0])
+
+
+def test_preview_collages_equal_the_reference_held_ones(gpu, tmp_path, hu_panels, capsys):
+    """main() with the production flags and --n_preview reproduces, pixel for pixel, the 21 preview collages
+    the reference's run left under reports/sample_images (1120 x 224: views 01, 05, 09, the cropped gray view,
+    its silhouette; all gray, R = G = B), from the three raw views each of them shows."""
+    from PIL import Image
+    hu = pkg("extract_2d_hu")
+    views, out, rep = tmp_path / "views", tmp_path / "2d_hu", tmp_path / "reports"
+    ids = hu_panels["ids"]
+    for s, sid in enumerate(ids):
+        d = views / sid
+        d.mkdir(parents=True)
+        for v, name in enumerate(("view_01.png", "view_05.png", "view_09.png")):
+            Image.fromarray(hu_panels["raw_views"][s, v]).save(d / name)
+    rc = hu.main(["--views_dir", str(views), "--out_dir", str(out), "--reports_dir", str(rep), "--preprocess_crop",
+                  "--use_silhouette", "--expected_views", "3", "--overwrite", "--n_preview", str(len(ids) + 5)])
+    assert rc == 0
+    for s, sid in enumerate(ids):
+        got = np.asarray(Image.open(rep / "sample_images" / f"{sid}_hu_preview.png"))
+        want = np.concatenate([hu_panels["raw_views"][s, 0], hu_panels["raw_views"][s, 1], hu_panels["raw_views"][s, 2],
+                               hu_panels["preproc"][s], hu_panels["masks"][s]], axis=1)
+        assert got.shape == (224, 1120, 3) and got.dtype == np.uint8
+        np.testing.assert_array_equal(got, np.repeat(want[:, :, None], 3, axis=2), err_msg=sid)
+    assert capsys.readouterr().out.count("[mask-clean]") == 5
+    # without --use_silhouette the last panel is the preprocessed image, binarised at 128 like every last panel
+    rc = hu.main(["--views_dir", str(views), "--out_dir", str(out), "--reports_dir", str(tmp_path / "rep2"),
+                  "--preprocess_crop", "--expected_views", "3", "--overwrite", "--n_preview", "2", "--max_samples", "2"])
+    assert rc == 0
+    first = sorted(ids)[0]
+    got = np.asarray(Image.open(tmp_path / "rep2" / "sample_images" / f"{first}_hu_preview.png"))
+    np.testing.assert_array_equal(got[:, 896:], np.where(got[:, 672:896] > 128, 255, 0).astype(np.uint8))
