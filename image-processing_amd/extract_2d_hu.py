@@ -50,9 +50,13 @@ def list_sample_ids(views_dir: Path) -> List[Tuple[str, Path]]:
     found = []
     if not views_dir.exists():
         return found
-    for d in sorted(views_dir.iterdir(), key=lambda p: str(p)):
-        if d.is_dir() and any(p.suffix.lower() in IMAGE_SUFFIXES for p in d.glob("*")):
-            found.append((d.name, d))
+    root = str(views_dir)
+    with os.scandir(root) as it:
+        dirs = sorted(os.path.join(root, e.name) for e in it if e.is_dir())   # (the order of str(path), as the reference's)
+    for d in dirs:
+        with os.scandir(d) as files:
+            if any(os.path.splitext(f.name)[1].lower() in IMAGE_SUFFIXES for f in files):
+                found.append((os.path.basename(d), Path(d)))
     return found
 
 
@@ -537,6 +541,9 @@ def finish_samples(decoded: Dict[str, Any]) -> List[Dict[str, Any]]:
                 if not results[k]["note"].startswith("failed"):
                     results[k]["note"] = f"failed: {e}"
 
+    # descriptor files of the whole batch through the native writer (one call; np.save for what it declines)
+    pending: List[tuple] = []   # (task, path, vector, files found)
+    made: set = set()
     for k, (sample_id, dir_path_str, config) in enumerate(tasks):
         res = results[k]
         n_files = res.pop("_n_files", 0)
@@ -545,10 +552,26 @@ def finish_samples(decoded: Dict[str, Any]) -> List[Dict[str, Any]]:
         try:
             if k not in stats_by_task:
                 raise RuntimeError("No usable views for Hu computation")
-            vec = stats_by_task[k].astype(np.float32)
             out_dir = Path(config["out_dir"])
-            ensure_dir(out_dir)
-            np.save(str(out_dir / f"{sample_id}_hu.npy"), vec, allow_pickle=False)
+            if str(out_dir) not in made:
+                ensure_dir(out_dir)
+                made.add(str(out_dir))
+            pending.append((k, str(out_dir / f"{sample_id}_hu.npy"), stats_by_task[k].astype(np.float32), n_files))
+        except Exception as e:
+            _log_error(Path(config.get("reports_dir", "reports")), dir_path_str, type(e).__name__, e)
+            res["note"] = f"failed: {e}"
+    status = np.zeros(0, dtype=np.int32)
+    if pending:
+        try:
+            status = ingest.write_rows_batch([p[1] for p in pending], np.stack([p[2] for p in pending]), decoded["workers"])
+        except Exception:
+            status = np.ones(len(pending), dtype=np.int32)
+    for j, (k, path, vec, n_files) in enumerate(pending):
+        sample_id, dir_path_str, config = tasks[k]
+        res = results[k]
+        try:
+            if status[j] != 0:
+                np.save(path, vec, allow_pickle=False)
             note = "partial_views" if n_files < int(config["expected_views"]) else "ok"
             res.update({"success": True, "vec": vec.tolist(), "note": note})
         except Exception as e:

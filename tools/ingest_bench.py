@@ -34,6 +34,9 @@ def main():
     ap.add_argument("--dir", default=None)
     ap.add_argument("--batch_samples", type=int, default=256)
     ap.add_argument("--repeats", type=int, default=3)
+    ap.add_argument("--kind", default="rendered", choices=["rendered", "noisy"],
+                    help="views: renderings of synthetic clouds (what the reference's run reads: dark markers on white, "
+                         "a few KB per PNG) or noisy gray shapes (the worst case for the inflate: 35 KB per PNG)")
     a = ap.parse_args()
 
     eng = importlib.import_module("image-processing_amd.engine")
@@ -44,11 +47,19 @@ def main():
     try:
         # ---- data set
         n_img = a.samples * a.views
-        shapes = eng.synth_shapes(n_img, 224, 224, seed=7, device=dev).to(torch.float32)
-        g = torch.Generator(device=dev)
-        g.manual_seed(7)
-        gray = (235.0 - shapes * (195.0 / 255.0) + torch.randn(shapes.shape, generator=g, device=dev) * 8.0)
-        gray = gray.clamp_(0, 255).round_().to(torch.uint8).cpu().numpy()
+        if a.kind == "rendered":
+            rv = importlib.import_module("image-processing_amd.render_views")
+            cl = eng.synth_points(a.samples, 1024, seed=11, device=dev).reshape(-1, 3).contiguous()
+            off = torch.arange(a.samples + 1, dtype=torch.int64, device=dev) * 1024
+            parts = [rv.render_views_device(cl, off[i:i + 501], a.views, 224) for i in range(0, a.samples, 500)]
+            gray = torch.cat(parts).reshape(n_img, 224, 224).cpu().numpy()
+            del parts, cl
+        else:
+            shapes = eng.synth_shapes(n_img, 224, 224, seed=7, device=dev).to(torch.float32)
+            g = torch.Generator(device=dev)
+            g.manual_seed(7)
+            gray = (235.0 - shapes * (195.0 / 255.0) + torch.randn(shapes.shape, generator=g, device=dev) * 8.0)
+            gray = gray.clamp_(0, 255).round_().to(torch.uint8).cpu().numpy()
         views = root / "views"
         for s in range(a.samples):
             (views / f"tree_{s:05d}").mkdir(parents=True)
@@ -75,7 +86,7 @@ def main():
         eng.pca_batch(torch.zeros((2, 1024, 3), device=dev))
         torch.cuda.synchronize()
 
-        out = {"views": n_img, "clouds": a.clouds, "workers": a.workers, "png_bytes": png_bytes,
+        out = {"kind": a.kind, "views": n_img, "clouds": a.clouds, "workers": a.workers, "png_bytes": png_bytes,
                "batch_samples": a.batch_samples, "png_on_device": hu.png_on_device()}
         import pandas  # noqa: F401  (0.3 s of imports that main() would otherwise do inside the timed call)
         import yaml  # noqa: F401
