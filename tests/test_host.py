@@ -471,3 +471,22 @@ def test_class_codes_follow_sorted_labels():
     b = pkg("binarize")
     classes, codes = b.class_codes(np.array(["oak", "ash", "oak", "fir"]))
     assert classes == ["ash", "fir", "oak"] and codes.tolist() == [2, 0, 2, 1] and codes.dtype == np.int32
+
+
+def test_npy_listing_equals_pathlib(tmp_path):
+    """list_npy_files against the expression it replaces: nested directories, other suffixes, a directory
+    named like a file, links to a file and to a directory, a broken link."""
+    import os
+    pca = pkg("extract_3d_pca_features")
+    root = tmp_path / "sampled"
+    (root / "b" / "deep").mkdir(parents=True)
+    (root / "a").mkdir()
+    (root / "dir.npy").mkdir()
+    for rel in ("z.npy", "a/x.npy", "a/x.NPY", "a/y.txt", "b/deep/q.npy", "b/.npy", "dir.npy/inner.npy"):
+        (root / rel).write_bytes(b"x")
+    os.symlink(root / "z.npy", root / "a" / "link.npy")
+    os.symlink(root / "b", root / "linked_dir")
+    os.symlink(root / "missing.npy", root / "broken.npy")
+    want = sorted((p for p in root.rglob("*.npy") if p.is_file()), key=lambda p: str(p))
+    assert pca.list_npy_files(root) == want
+    assert len(want) == 6
