@@ -2074,8 +2074,8 @@ __device__ __forceinline__ int64_t pca_set_size(const PcaArgs &A, int64_t set)
 }
 
 constexpr int CLASSIFY_THREADS = 1024, CLASSIFY_WAVES = CLASSIFY_THREADS / FX_WAVE;
-// mode 1: every set goes to the cloud list (float64 input); mode 2: every set that is no large cloud goes to the
-// register list (batches of few sets, see launch_ragged_on_device)
+// mode 1: every set goes to the cloud list (float64 input).  (Batches of few sets are classified by
+// pca_few_prepare_kernel.)
 __global__ __launch_bounds__(CLASSIFY_THREADS) void pca_classify_kernel(PcaArgs A, RaggedLists L, int64_t B, int64_t reg_max,
                                                                        int mode)
 {
@@ -2095,7 +2095,6 @@ __global__ __launch_bounds__(CLASSIFY_THREADS) void pca_classify_kernel(PcaArgs 
         bad = A.offsets && L.total > 0 && (A.offsets[b] < 0 || A.offsets[b + 1] > L.total);
         if (!bad)
             cls = mode == 1 ? 2
-                  : mode == 2 ? (n <= WAVE_SET_MAX_POINTS ? 0 : 2)
                   : n <= QUAD_LANES * 4 ? 5
                   : n <= QUAD_LANES * 8 ? 4
                   : n <= QUAD_MAX_POINTS ? 3
