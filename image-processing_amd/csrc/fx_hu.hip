@@ -968,8 +968,17 @@ __global__ __launch_bounds__(FX_BLOCK, FX_BAND_WAVES) void hu_band_kernel(HuArgs
     const int bl = lane / cpr, tx = lane - bl * cpr;
     const int x0 = tx * 16;
     const bool active = bl < A.bpw && x0 < W;
+    // Moments only (SWEEP): the block sweeps the image from top to bottom, 16 * bpw consecutive rows a step --
+    // a wave-load takes bpw consecutive rows, a wave its four loads in flight, the four waves one after the
+    // other -- so the block reads at one place (16 KB of a 512-pixel-wide image per step).  A read-only kernel
+    // with this pattern streams 7.1-7.2 TB/s on this device; with bands per lane group, eight places of 512
+    // bytes at once per block, 6.6 TB/s (tools/ubench/stream_read.hip).  A lane's rows are then
+    // ya + (uniform row offset), which is all the moment sums ask for.  The contour variant keeps the bands: a
+    // lane needs the rows above and below its own.  So do the 1024 x 256 tiles of larger images, whose rows are
+    // a pitch apart whichever way a block walks them: 64 x 8192 x 8192, 0.64 ms with bands, 0.70 ms swept.
+    const bool SWEEP = !CONTOUR && A.tiles_x == 0;   // (block-uniform)
     const int band = wave * A.bpw + bl;
-    const int ya = band * hb;
+    const int ya = SWEEP ? wave * 4 * A.bpw + bl : band * hb;
     const uint32_t kthr = (uint32_t)(255 - (A.thresh < 0 ? 127 : A.thresh)) * 0x00010001u;
 
     // ALIGNED == 2: buffer loads.  The descriptor of a row (scalar registers, built by the scalar unit)
@@ -990,14 +999,14 @@ __global__ __launch_bounds__(FX_BLOCK, FX_BAND_WAVES) void hu_band_kernel(HuArgs
             // signed and through max(): an unsigned saturating subtraction exists only on the vector
             // unit, and a descriptor word in a vector register wraps every load in a loop over lanes
             const int left = max((int)span - (int)roff, 0);
-            const int records = __builtin_amdgcn_readfirstlane(r < hb ? left : 0);
+            const int records = __builtin_amdgcn_readfirstlane(SWEEP || r < hb ? left : 0);
             const __amdgpu_buffer_rsrc_t rsrc =
                 __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(img) + roff, 0, records, 0x00020000);
             const band_u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 2 /* nt */);
             return make_uint4(q.x, q.y, q.z, q.w);
         }
         const int y = ya + r;
-        const bool valid = active && r < hb && y < H;
+        const bool valid = active && (SWEEP || r < hb) && y < H;
         if (ALIGNED == 1) {
             const int yc = valid ? y : 0;
             const int xc = active ? x0 : 0;
@@ -1128,7 +1137,30 @@ __global__ __launch_bounds__(FX_BLOCK, FX_BAND_WAVES) void hu_band_kernel(HuArgs
             }
         }
     };
-    if (hb <= SUB) {
+    if (SWEEP) {
+        // 32-bit partial sums over segments of SUB rows (or one step, where a step is more than that): the row
+        // offset within the segment is the wave-uniform factor of the weighted sums
+        const int rpl = A.bpw, step_rows = 16 * rpl;
+        const int seg_steps = SUB / step_rows > 1 ? SUB / step_rows : 1;
+        for (int base = 0; base < H; base += seg_steps * step_rows) {
+            Acc32 a;
+            a.clear();
+#pragma unroll 1
+            for (int ss = 0; ss < seg_steps && base + ss * step_rows < H; ss++) {
+                const int j0 = ss * step_rows, r0 = base + j0;
+                uint4 v0 = load_chunk(r0);
+                uint4 v1 = load_chunk(r0 + rpl);
+                uint4 v2 = load_chunk(r0 + 2 * rpl);
+                uint4 v3 = load_chunk(r0 + 3 * rpl);
+                uint32_t b0, b1, b2, b3;
+                chunk_sums<MODE, TAB>(v0, kthr, j0, a, b0, tab);
+                chunk_sums<MODE, TAB>(v1, kthr, j0 + rpl, a, b1, tab);
+                chunk_sums<MODE, TAB>(v2, kthr, j0 + 2 * rpl, a, b2, tab);
+                chunk_sums<MODE, TAB>(v3, kthr, j0 + 3 * rpl, a, b3, tab);
+            }
+            flush_band(a, (uint32_t)(ya + base), T);
+        }
+    } else if (hb <= SUB) {
         Acc32 a;
         a.clear();
         run_rows(0, a);
@@ -1468,6 +1500,9 @@ int launch_image_kernel(const HuArgs &A, bool aligned, size_t lds, hipStream_t s
     return FX_OK;
 }
 
+#ifndef FX_SWEEP_HB
+#define FX_SWEEP_HB 0   // the moments-only kernel (block sweep) takes the buffer loads
+#endif
 // How the band kernel reads the rows (its ALIGNED parameter).  The buffer loads address a row as a
 // 32-bit offset from the image's (tile's) first pixel; they pay for bands of fewer than 64 rows.
 inline int band_aligned(bool aligned, int W, int H, int64_t pitch_bytes, int hb)
@@ -1662,6 +1697,8 @@ int hu_batch_impl(const char *who, const HuScratch &scratch, const uint8_t *d_im
     }
 
     A.bpw = FX_WAVE / A.cpr;
+    if (!contour && mode == MODE_GRAY && A.bpw > 16)
+        A.bpw = 16;   // (gray weights, images up to 48 pixels wide: more rows per step would overflow the 32-bit partial sums)
     A.nbands = A.bpw * FX_WAVES_PER_BLOCK;
     A.hb = (H + A.nbands - 1) / A.nbands;
     // every wave could meet all segments of its bands: cap per wave, four waves
@@ -1695,7 +1732,7 @@ int hu_batch_impl(const char *who, const HuScratch &scratch, const uint8_t *d_im
     int rc;
     {
         FxProfileScope prof(s);
-        rc = launch_band(A, G, mode, contour, band_aligned(aligned, W, H, pitch_bytes, A.hb), band_lds, s);
+        rc = launch_band(A, G, mode, contour, band_aligned(aligned, W, H, pitch_bytes, contour ? A.hb : FX_SWEEP_HB), band_lds, s);
     }
     if (rc != FX_OK)
         return rc;

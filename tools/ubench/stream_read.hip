@@ -1,0 +1,128 @@
+// What a kernel that only reads can stream from HBM on this device: every block reads its own contiguous
+// segment with 16-byte loads, U loads per lane in flight, and folds the data into one word.  Variants: plain or
+// non-temporal loads, a block per segment or a resident grid that walks the segments.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <cstdlib>
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <int U, bool NT, bool WALK>
+__global__ __launch_bounds__(256) void read_kernel(const u32x4 *buf, int64_t seg_vec, int64_t n_seg, uint32_t *out)
+{
+    uint32_t acc = 0;
+    for (int64_t seg = blockIdx.x; seg < n_seg; seg += WALK ? gridDim.x : n_seg) {
+        const u32x4 *p = buf + seg * seg_vec;
+        for (int64_t i = threadIdx.x; i < seg_vec; i += 256 * U) {
+            u32x4 v[U];
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                const int64_t j = i + 256 * k;
+                const u32x4 *q = p + (j < seg_vec ? j : i);
+                v[k] = NT ? __builtin_nontemporal_load(q) : *q;
+            }
+#pragma unroll
+            for (int k = 0; k < U; k++)
+                acc ^= v[k].x ^ v[k].y ^ v[k].z ^ v[k].w;
+        }
+    }
+    if (acc == 0x12345678u)
+        out[blockIdx.x] = acc;
+}
+// The band kernel's pattern on a 512 x 512 image (a segment of 256 KB): eight bands of 64 rows, a band per
+// 32 lanes, four rows of a band in flight -- a block reads at eight places at once, 512 bytes each.
+// PAIR: the two halves of a wave take adjacent rows instead (a wave reads 1 KB at one place, four waves at four).
+template <bool PAIR>
+__global__ __launch_bounds__(256) void band_kernel(const u32x4 *buf, int64_t seg_vec, int64_t n_seg, uint32_t *out)
+{
+    uint32_t acc = 0;
+    const u32x4 *p = buf + (int64_t)blockIdx.x * seg_vec;
+    const int t = threadIdx.x, tx = t & 31;
+    if (!PAIR) {
+        const int band = t >> 5;
+        for (int r = 0; r < 64; r += 4) {
+            u32x4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                v[k] = __builtin_nontemporal_load(p + (int64_t)(band * 64 + r + k) * 32 + tx);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                acc ^= v[k].x ^ v[k].y ^ v[k].z ^ v[k].w;
+        }
+    } else {
+        const int wave = t >> 6, half = (t >> 5) & 1;
+        for (int r = 0; r < 128; r += 8) {
+            u32x4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                v[k] = __builtin_nontemporal_load(p + (int64_t)(wave * 128 + r + 2 * k + half) * 32 + tx);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                acc ^= v[k].x ^ v[k].y ^ v[k].z ^ v[k].w;
+        }
+    }
+    if (acc == 0x12345678u)
+        out[blockIdx.x] = acc;
+}
+template <bool PAIR>
+void run_band(const char *name, const u32x4 *buf, int64_t bytes, uint32_t *out)
+{
+    const int64_t seg_bytes = 262144, seg_vec = seg_bytes / 16, n_seg = bytes / seg_bytes;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0), (void)hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; rep++) {
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL((band_kernel<PAIR>), dim3((unsigned)n_seg), dim3(256), 0, 0, buf, seg_vec, n_seg, out);
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+        float ms;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (rep && ms < best)
+            best = ms;
+    }
+    printf("%-44s segment %5lld KB: %7.3f ms  %6.0f GB/s\n", name, (long long)(seg_bytes >> 10), best, bytes / best / 1e6);
+}
+template <int U, bool NT, bool WALK>
+void run(const char *name, const u32x4 *buf, int64_t bytes, int64_t seg_bytes, uint32_t *out, int cus)
+{
+    const int64_t seg_vec = seg_bytes / 16, n_seg = bytes / seg_bytes;
+    const int grid = WALK ? cus * 8 : (int)n_seg;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0), (void)hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; rep++) {
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL((read_kernel<U, NT, WALK>), dim3(grid), dim3(256), 0, 0, buf, seg_vec, n_seg, out);
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+        float ms;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (rep && ms < best)
+            best = ms;
+    }
+    printf("%-44s segment %5lld KB: %7.3f ms  %6.0f GB/s\n", name, (long long)(seg_bytes >> 10), best, bytes / best / 1e6);
+}
+int main(int argc, char **argv)
+{
+    const int64_t bytes = (argc > 1 ? atoll(argv[1]) : 16) << 30;
+    hipDeviceProp_t p;
+    (void)hipGetDeviceProperties(&p, 0);
+    u32x4 *buf;
+    uint32_t *out;
+    if (hipMalloc(&buf, bytes) != hipSuccess || hipMalloc(&out, 1 << 22) != hipSuccess)
+        return 1;
+    (void)hipMemset(buf, 1, bytes);
+    const int cus = p.multiProcessorCount;
+    run_band<false>("nt, eight bands of 64 rows per block", buf, bytes, out);
+    run_band<true>("nt, four bands of 128 rows, halves on adjacent rows", buf, bytes, out);
+    for (int64_t seg : {65536ll, 262144ll, 1048576ll}) {
+        run<4, false, false>("plain, 4 in flight, block per segment", buf, bytes, seg, out, cus);
+        run<4, true, false>("nt,    4 in flight, block per segment", buf, bytes, seg, out, cus);
+        run<8, true, false>("nt,    8 in flight, block per segment", buf, bytes, seg, out, cus);
+        run<16, true, false>("nt,   16 in flight, block per segment", buf, bytes, seg, out, cus);
+        run<4, true, true>("nt,    4 in flight, resident grid", buf, bytes, seg, out, cus);
+        run<8, true, true>("nt,    8 in flight, resident grid", buf, bytes, seg, out, cus);
+        run<8, false, true>("plain, 8 in flight, resident grid", buf, bytes, seg, out, cus);
+    }
+    return 0;
+}
