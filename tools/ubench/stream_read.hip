@@ -31,6 +31,25 @@ __global__ __launch_bounds__(256) void read_kernel(const u32x4 *buf, int64_t seg
 // The band kernel's pattern on a 512 x 512 image (a segment of 256 KB): eight bands of 64 rows, a band per
 // 32 lanes, four rows of a band in flight -- a block reads at eight places at once, 512 bytes each.
 // PAIR: the two halves of a wave take adjacent rows instead (a wave reads 1 KB at one place, four waves at four).
+// Column strips: wave w takes the 128-byte quarter w of every row of the 512-byte-wide image, eight rows a load,
+// four loads in flight; the four waves walk down side by side (if they stay together, 16 KB at one place).
+__global__ __launch_bounds__(256) void strip_kernel(const u32x4 *buf, int64_t seg_vec, int64_t n_seg, uint32_t *out)
+{
+    uint32_t acc = 0;
+    const u32x4 *p = buf + (int64_t)blockIdx.x * seg_vec;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, tx = lane & 7, bl = lane >> 3;
+    for (int r = 0; r < 512; r += 32) {
+        u32x4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            v[k] = __builtin_nontemporal_load(p + (int64_t)(r + 8 * k + bl) * 32 + wave * 8 + tx);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            acc ^= v[k].x ^ v[k].y ^ v[k].z ^ v[k].w;
+    }
+    if (acc == 0x12345678u)
+        out[blockIdx.x] = acc;
+}
 template <bool PAIR>
 __global__ __launch_bounds__(256) void band_kernel(const u32x4 *buf, int64_t seg_vec, int64_t n_seg, uint32_t *out)
 {
@@ -113,6 +132,23 @@ int main(int argc, char **argv)
         return 1;
     (void)hipMemset(buf, 1, bytes);
     const int cus = p.multiProcessorCount;
+    {
+        const int64_t seg_vec = 262144 / 16, n_seg = bytes / 262144;
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0), (void)hipEventCreate(&e1);
+        float best = 1e30f;
+        for (int rep = 0; rep < 4; rep++) {
+            (void)hipEventRecord(e0);
+            hipLaunchKernelGGL(strip_kernel, dim3((unsigned)n_seg), dim3(256), 0, 0, buf, seg_vec, n_seg, out);
+            (void)hipEventRecord(e1);
+            (void)hipEventSynchronize(e1);
+            float ms;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            if (rep && ms < best)
+                best = ms;
+        }
+        printf("%-44s segment   256 KB: %7.3f ms  %6.0f GB/s\n", "nt, four column strips of 128 bytes", best, bytes / best / 1e6);
+    }
     run_band<false>("nt, eight bands of 64 rows per block", buf, bytes, out);
     run_band<true>("nt, four bands of 128 rows, halves on adjacent rows", buf, bytes, out);
     for (int64_t seg : {65536ll, 262144ll, 1048576ll}) {
