@@ -684,7 +684,7 @@ __global__ __launch_bounds__(FX_BLOCK) void hu_image_kernel(HuArgs A)
 // moments, Hu, log, the descriptor's nine leading scalars -- serial float64
 // code that would idle 255 of 256 threads inside the streaming kernel).
 constexpr int BAND_LDS_COUNTERS = LDS_HEAD_BYTES;          // 16 B: segments queued by each wave
-constexpr int BAND_LDS_EDGES = BAND_LDS_COUNTERS + 16;     // top/bottom row masks of every band; later 4 x 64 histogram counters
+constexpr int BAND_LDS_EDGES = BAND_LDS_COUNTERS + 16;     // 4 x 64 histogram counters of the contour tail
 // the lookup table of the 0/1-weighted modes at a fixed offset (the lookups then address it with an
 // immediate), behind it the four reduction slabs of the contour variant, then the per-wave regions:
 // the wave's part of the segment queue (contour variant) or the 4 KiB slab of the wave-level
@@ -756,7 +756,6 @@ __device__ __forceinline__ void band_contour_hist(const HuArgs &A, const int64_t
     // other three fetch its four results from LDS instead of repeating it.
     uint32_t *hist_all = reinterpret_cast<uint32_t *>(lds_raw + BAND_LDS_EDGES);
     uint32_t *hist = hist_all + wave * FX_WAVE;
-    // the edge rows have been exchanged before the last barrier: their LDS holds the four histograms now
     hist[lane] = 0;
     if (wave == 0) {
         u64 cs[6];
@@ -934,8 +933,6 @@ __global__ __launch_bounds__(FX_BLOCK, FX_BAND_WAVES) void hu_band_kernel(HuArgs
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     u64 *red = reinterpret_cast<u64 *>(lds_raw);
-    uint16_t *edge_top = reinterpret_cast<uint16_t *>(lds_raw + BAND_LDS_EDGES);
-    uint16_t *edge_bot = edge_top + FX_BLOCK;
     const int wave_bytes = A.wave_lds;  // >= BAND_SLAB_BYTES
 
     const int t = threadIdx.x;
@@ -973,10 +970,11 @@ __global__ __launch_bounds__(FX_BLOCK, FX_BAND_WAVES) void hu_band_kernel(HuArgs
     // other -- so the block reads at one place (16 KB of a 512-pixel-wide image per step).  A read-only kernel
     // with this pattern streams 7.1-7.2 TB/s on this device; with bands per lane group, eight places of 512
     // bytes at once per block, 6.6 TB/s (tools/ubench/stream_read.hip).  A lane's rows are then
-    // ya + (uniform row offset), which is all the moment sums ask for.  The contour variant keeps the bands: a
-    // lane needs the rows above and below its own.  So do the 1024 x 256 tiles of larger images, whose rows are
-    // a pitch apart whichever way a block walks them: 64 x 8192 x 8192, 0.64 ms with bands, 0.70 ms swept.
-    const bool SWEEP = !CONTOUR && A.tiles_x == 0;   // (block-uniform)
+    // ya + (uniform row offset), which is all the moment sums ask for; the contour detection, which needs the
+    // rows above and below a row, gets them through LDS (below).  The 1024 x 256 tiles of larger images keep
+    // the bands (a band of hb consecutive rows per group of cpr lanes): their rows are a pitch apart whichever
+    // way a block walks them, 64 x 8192 x 8192 take 0.64 ms with bands and 0.70 ms swept.
+    const bool SWEEP = CONTOUR || A.tiles_x == 0;   // (block-uniform; tiles carry no contour descriptor)
     const int band = wave * A.bpw + bl;
     const int ya = SWEEP ? wave * 4 * A.bpw + bl : band * hb;
     const uint32_t kthr = (uint32_t)(255 - (A.thresh < 0 ? 127 : A.thresh)) * 0x00010001u;
@@ -1037,6 +1035,7 @@ __global__ __launch_bounds__(FX_BLOCK, FX_BAND_WAVES) void hu_band_kernel(HuArgs
     const int wcap = A.qcap >> 2;
     uint32_t *wq = reinterpret_cast<uint32_t *>(lds_raw + band_lds_wave(CONTOUR) + wave * wave_bytes);
     uint32_t wn = 0;  // wave-uniform: segments this wave has queued (may run past wcap: overflow)
+    int ybase = ya;   // the lane's part of a queued segment's row (the sweep with contours sets its own)
     auto push = [&](int r, uint32_t bits) {
         const unsigned long long m = __ballot(bits != 0);
         if (m) {
@@ -1046,7 +1045,7 @@ __global__ __launch_bounds__(FX_BLOCK, FX_BAND_WAVES) void hu_band_kernel(HuArgs
             // the room is checked for the wave as a whole (scalar): a wave that runs out of it stores
             // nothing more, and its count past the limit sends the image to the mask kernel
             if (after <= (uint32_t)wcap && bits)
-                wq[idx] = bits | ((uint32_t)(((ya + r) << 6) | tx) << 16);
+                wq[idx] = bits | ((uint32_t)(((ybase + r) << 6) | tx) << 16);
             wn = after;
         }
     };
@@ -1057,7 +1056,7 @@ __global__ __launch_bounds__(FX_BLOCK, FX_BAND_WAVES) void hu_band_kernel(HuArgs
     // rp+1 << 16, P1 likewise; above = row rp-1, below = row rp+4.  Rows 0 and
     // hb-1 of the band are left out here: their outer neighbour row belongs to
     // another band.  Must be called by every lane of the wave.
-    auto detect4 = [&](int rp, uint32_t above, uint32_t P0, uint32_t P1, uint32_t below) {
+    auto contour_bits = [&](uint32_t above, uint32_t P0, uint32_t P1, uint32_t below, uint32_t &B0, uint32_t &B1) {
         const uint32_t up0 = (P0 << 16) | above;
         const uint32_t dn0 = (P0 >> 16) | (P1 << 16);
         const uint32_t up1 = (P1 << 16) | (P0 >> 16);
@@ -1077,34 +1076,21 @@ __global__ __launch_bounds__(FX_BLOCK, FX_BAND_WAVES) void hu_band_kernel(HuArgs
         const uint32_t rb1 = (ER << 13) & 0x80008000u;
         const uint32_t left0 = ((P0 << 1) & 0xFFFEFFFEu) | lb0, right0 = ((P0 >> 1) & 0x7FFF7FFFu) | rb0;
         const uint32_t left1 = ((P1 << 1) & 0xFFFEFFFEu) | lb1, right1 = ((P1 >> 1) & 0x7FFF7FFFu) | rb1;
-        const uint32_t B0 = P0 & ~(up0 & dn0 & left0 & right0);
-        const uint32_t B1 = P1 & ~(up1 & dn1 & left1 & right1);
-        const int last = hb - 1;
-        if (rp > 0 && rp < last)
-            push(rp, B0 & 0xFFFFu);
-        if (rp + 1 < last)
-            push(rp + 1, B0 >> 16);
-        if (rp + 2 < last)
-            push(rp + 2, B1 & 0xFFFFu);
-        if (rp + 3 < last)
-            push(rp + 3, B1 >> 16);
+        B0 = P0 & ~(up0 & dn0 & left0 & right0);
+        B1 = P1 & ~(up1 & dn1 & left1 & right1);
     };
-    // One row with explicit neighbours (the band's first and last row).
-    auto detect1 = [&](int r, uint32_t up, uint32_t cur, uint32_t dn) {
-        uint32_t lc = __builtin_amdgcn_update_dpp(0u, cur, 0x138, 0xf, 0xf, false);
-        uint32_t rc = __builtin_amdgcn_update_dpp(0u, cur, 0x130, 0xf, 0xf, false);
-        const uint32_t lbit = has_left ? (lc >> 15) & 1u : 0u;
-        const uint32_t rbit = has_right ? (rc & 1u) : 0u;
-        const uint32_t left = ((cur << 1) | lbit) & 0xFFFFu;
-        const uint32_t right = (cur >> 1) | (rbit << 15);
-        push(r, cur & ~(up & dn & left & right));
+    // the same for the sweep: rows ybase + rp .. + 3 of the lane's group, none left out (a row above the
+    // image or below it has no foreground, so it queues nothing)
+    auto detect4s = [&](int rp, uint32_t above, uint32_t P0, uint32_t P1, uint32_t below) {
+        uint32_t B0, B1;
+        contour_bits(above, P0, P1, below, B0, B1);
+        push(rp, B0 & 0xFFFFu);
+        push(rp + 1, B0 >> 16);
+        push(rp + 2, B1 & 0xFFFFu);
+        push(rp + 3, B1 >> 16);
     };
-
     Tot64 T;
     T.clear();
-    // detection runs one group of four rows behind the loads: it needs the
-    // first row of the next group as the row below
-    uint32_t pend0 = 0, pend1 = 0, pend_above = 0, c_first = 0, c_second = 0;
 
     // Rows per flush of the 32-bit partial sums.  With 0/1 weights (binary
     // modes) they are 255 times smaller than with gray weights and can run over
@@ -1124,20 +1110,81 @@ __global__ __launch_bounds__(FX_BLOCK, FX_BAND_WAVES) void hu_band_kernel(HuArgs
             chunk_sums<MODE, TAB>(v1, kthr, j + 1, a, b1, tab);
             chunk_sums<MODE, TAB>(v2, kthr, j + 2, a, b2, tab);
             chunk_sums<MODE, TAB>(v3, kthr, j + 3, a, b3, tab);
-            if (CONTOUR) {
-                if (r == 0) {
-                    c_first = b0;
-                    c_second = b1;
-                } else {
-                    detect4(r - 4, pend_above, pend0, pend1, b0);
-                    pend_above = pend1 >> 16;
-                }
-                pend0 = b0 | (b1 << 16);
-                pend1 = b2 | (b3 << 16);
-            }
         }
     };
-    if (SWEEP) {
+    if (CONTOUR) {
+        // The sweep with contours.  A lane's four rows of a step lie rpl rows apart, and the rows above and
+        // below a wave's stretch belong to other waves: the row masks of a step go through LDS, a column of
+        // 16-bit masks per chunk column, rows one after the other, and come back as windows of six consecutive
+        // rows -- lane group g = wave * rpl + bl takes the rows 4 g - 1 .. 4 g + 2 of the step (one row behind,
+        // so that the row below the last one is there), with the row above and the row below.  Three stretches
+        // of a step's rows per column in turn: a step reads its own and the last two rows of the one before,
+        // and writes nothing a wave one block barrier behind may still read.  One block barrier per step; the
+        // next step's loads are issued before it.
+        const int rpl = A.bpw, step_rows = 16 * rpl;
+        const int steps = (H + step_rows - 1) / step_rows;
+        const int seg_steps = SUB / step_rows > 1 ? SUB / step_rows : 1;
+        const int col_bytes = (3 * step_rows + 2) * 2;   // (an odd number of 32-bit words: the columns spread over the banks)
+        unsigned char *ring = lds_raw + BAND_LDS_CSLAB + tx * col_bytes;   // this lane's column (the slabs are free until the block sums)
+        const int group = wave * rpl + bl;   // rows 4 group - 1 .. 4 group + 2 of a step
+        ybase = 4 * group - 1;
+        const int my_slot = wave * 4 * rpl + bl;   // the lane's first row within a step
+        uint4 v0 = load_chunk(0), v1 = load_chunk(rpl), v2 = load_chunk(2 * rpl), v3 = load_chunk(3 * rpl);
+        if (active && group == 0)   // the two rows above the image, which the first step finds at the end of the third stretch
+            *reinterpret_cast<uint32_t *>(reinterpret_cast<uint16_t *>(ring) + 3 * step_rows - 2) = 0u;
+        Acc32 a;
+        a.clear();
+        int seg_base = 0, region = 0;   // region: which third of a column this step writes
+        for (int s = 0; s < steps; s++) {
+            const int j0 = s * step_rows - seg_base;
+            uint32_t b0, b1, b2, b3;
+            chunk_sums<MODE, TAB>(v0, kthr, j0, a, b0, tab);
+            chunk_sums<MODE, TAB>(v1, kthr, j0 + rpl, a, b1, tab);
+            chunk_sums<MODE, TAB>(v2, kthr, j0 + 2 * rpl, a, b2, tab);
+            chunk_sums<MODE, TAB>(v3, kthr, j0 + 3 * rpl, a, b3, tab);
+            if (s + 1 < steps) {
+                const int r0 = (s + 1) * step_rows;
+                v0 = load_chunk(r0), v1 = load_chunk(r0 + rpl), v2 = load_chunk(r0 + 2 * rpl), v3 = load_chunk(r0 + 3 * rpl);
+            }
+            if ((s + 1) % seg_steps == 0 || s + 1 == steps) {
+                flush_band(a, (uint32_t)(ya + seg_base), T);
+                a.clear();
+                seg_base = (s + 1) * step_rows;
+            }
+            if (active) {
+                uint16_t *mine = reinterpret_cast<uint16_t *>(ring) + region * step_rows + my_slot;
+                mine[0] = (uint16_t)b0;
+                mine[rpl] = (uint16_t)b1;
+                mine[2 * rpl] = (uint16_t)b2;
+                mine[3 * rpl] = (uint16_t)b3;
+            }
+            __syncthreads();
+            {
+                // rows 4 group - 2 .. 4 group + 3 of the step; for group 0 the first two are the last rows of the step before
+                const int prev = region == 0 ? 2 : region - 1;
+                const int first = group == 0 ? prev * step_rows + step_rows - 2 : region * step_rows + 4 * group - 2;
+                const uint16_t *col = reinterpret_cast<const uint16_t *>(ring);
+                uint32_t w0 = 0, w1 = 0, w2 = 0;
+                if (active) {
+                    w0 = *reinterpret_cast<const uint32_t *>(col + first);
+                    const uint32_t *rest = reinterpret_cast<const uint32_t *>(col + region * step_rows + 4 * group);
+                    w1 = rest[0];
+                    w2 = rest[1];
+                }
+                detect4s(s * step_rows, w0 & 0xFFFFu, __builtin_amdgcn_alignbit(w1, w0, 16), __builtin_amdgcn_alignbit(w2, w1, 16), w2 >> 16);
+            }
+            region = region == 2 ? 0 : region + 1;
+        }
+        // the last row of the last step (if it is a row of the image): group 0 finds it, and the row above it,
+        // at the end of the stretch the last step wrote (every wave has passed that step's barrier)
+        if (steps * step_rows - 1 < H) {
+            const int prev = region == 0 ? 2 : region - 1;
+            const uint16_t *col = reinterpret_cast<const uint16_t *>(ring);
+            const uint32_t w0 = active && group == 0 ? *reinterpret_cast<const uint32_t *>(col + prev * step_rows + step_rows - 2) : 0u;
+            detect4s(steps * step_rows, w0 & 0xFFFFu, w0 >> 16, 0u, 0u);
+        }
+        __syncthreads();   // the columns lie where the block sums' slabs are
+    } else if (SWEEP) {
         // 32-bit partial sums over segments of SUB rows (or one step, where a step is more than that): the row
         // offset within the segment is the wave-uniform factor of the weighted sums
         const int rpl = A.bpw, step_rows = 16 * rpl;
@@ -1195,28 +1242,6 @@ __global__ __launch_bounds__(FX_BLOCK, FX_BAND_WAVES) void hu_band_kernel(HuArgs
     }
 
     if (CONTOUR) {
-        // the last group of four rows: nothing of this band lies below it
-        const int rp = ((hb - 1) >> 2) << 2;
-        detect4(rp, pend_above, pend0, pend1, 0u);
-        // rows 0 and hb-1 miss their neighbour row in the adjacent band:
-        // exchange them through LDS
-        const int k = hb - 1 - rp;  // position of the band's last row in the last group
-        const uint32_t c_last = k == 0 ? (pend0 & 0xFFFFu) : k == 1 ? (pend0 >> 16) : k == 2 ? (pend1 & 0xFFFFu) : (pend1 >> 16);
-        const uint32_t c_prevlast = k == 0 ? pend_above : k == 1 ? (pend0 & 0xFFFFu) : k == 2 ? (pend0 >> 16) : (pend1 & 0xFFFFu);
-        edge_top[t] = (uint16_t)c_first;
-        edge_bot[t] = (uint16_t)c_last;
-        __syncthreads();
-        // the thread that holds the same columns in the band above / below
-        const int above = t - cpr + ((bl == 0) ? (cpr * A.bpw - FX_WAVE) : 0);
-        const int below = t + cpr + ((bl == A.bpw - 1) ? (FX_WAVE - cpr * A.bpw) : 0);
-        const uint32_t up_ext = (active && band > 0) ? edge_bot[above] : 0u;
-        const uint32_t dn_ext = (active && band + 1 < A.nbands) ? edge_top[below] : 0u;
-        if (hb == 1) {
-            detect1(0, up_ext, c_first, dn_ext);
-        } else {
-            detect1(0, up_ext, c_first, c_second);
-            detect1(hb - 1, c_prevlast, c_last, dn_ext);
-        }
         // The wave reads back only its own part of the queue: LDS operations of
         // one wave complete in order, so no block barrier is needed here.
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1732,7 +1757,7 @@ int hu_batch_impl(const char *who, const HuScratch &scratch, const uint8_t *d_im
     int rc;
     {
         FxProfileScope prof(s);
-        rc = launch_band(A, G, mode, contour, band_aligned(aligned, W, H, pitch_bytes, contour ? A.hb : FX_SWEEP_HB), band_lds, s);
+        rc = launch_band(A, G, mode, contour, band_aligned(aligned, W, H, pitch_bytes, FX_SWEEP_HB), band_lds, s);
     }
     if (rc != FX_OK)
         return rc;
