@@ -50,6 +50,65 @@ __global__ __launch_bounds__(256) void strip_kernel(const u32x4 *buf, int64_t se
     if (acc == 0x12345678u)
         out[blockIdx.x] = acc;
 }
+// Point data: a thread takes four points (48 bytes) with three 16-byte loads, so an instruction touches a third
+// of every line it reads (V3 = false); or a point per lane with one 12-byte load, lanes side by side (V3 = true).
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+template <bool V3, bool NT>
+__global__ __launch_bounds__(256) void point_kernel(const u32x4 *buf, int64_t seg_vec, int64_t n_seg, uint32_t *out)
+{
+    uint32_t acc = 0;
+    const u32x4 *p = buf + (int64_t)blockIdx.x * seg_vec;
+    if (!V3) {
+        for (int64_t g = threadIdx.x; 3 * g + 2 < seg_vec; g += 256 * 4) {   // groups of four points, four groups in flight
+            u32x4 v[12];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int64_t gg = 3 * (g + 256 * k) + 2 < seg_vec ? g + 256 * k : g;
+#pragma unroll
+                for (int q = 0; q < 3; q++)
+                    v[3 * k + q] = NT ? __builtin_nontemporal_load(p + 3 * gg + q) : p[3 * gg + q];
+            }
+#pragma unroll
+            for (int k = 0; k < 12; k++)
+                acc ^= v[k].x ^ v[k].y ^ v[k].z ^ v[k].w;
+        }
+    } else {
+        const u32x3 *q3 = reinterpret_cast<const u32x3 *>(p);
+        const int64_t n_pts = seg_vec * 16 / 12;
+        for (int64_t i = threadIdx.x; i < n_pts; i += 256 * 16) {   // sixteen points in flight
+            u32x3 v[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int64_t j = i + 256 * k < n_pts ? i + 256 * k : i;
+                v[k] = NT ? __builtin_nontemporal_load(q3 + j) : q3[j];
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                acc ^= v[k].x ^ v[k].y ^ v[k].z;
+        }
+    }
+    if (acc == 0x12345678u)
+        out[blockIdx.x] = acc;
+}
+template <bool V3, bool NT>
+void run_points(const char *name, const u32x4 *buf, int64_t bytes, uint32_t *out)
+{
+    const int64_t seg_bytes = 98304, seg_vec = seg_bytes / 16, n_seg = bytes / seg_bytes;   // 8192 points
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0), (void)hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; rep++) {
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL((point_kernel<V3, NT>), dim3((unsigned)n_seg), dim3(256), 0, 0, buf, seg_vec, n_seg, out);
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+        float ms;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (rep && ms < best)
+            best = ms;
+    }
+    printf("%-44s segment %5lld KB: %7.3f ms  %6.0f GB/s\n", name, (long long)(seg_bytes >> 10), best, n_seg * seg_bytes / best / 1e6);
+}
 template <bool PAIR>
 __global__ __launch_bounds__(256) void band_kernel(const u32x4 *buf, int64_t seg_vec, int64_t n_seg, uint32_t *out)
 {
@@ -149,6 +208,10 @@ int main(int argc, char **argv)
         }
         printf("%-44s segment   256 KB: %7.3f ms  %6.0f GB/s\n", "nt, four column strips of 128 bytes", best, bytes / best / 1e6);
     }
+    run_points<false, false>("points, 3 x 16 B per thread, plain", buf, bytes, out);
+    run_points<false, true>("points, 3 x 16 B per thread, nt", buf, bytes, out);
+    run_points<true, false>("points, 12 B per lane, plain", buf, bytes, out);
+    run_points<true, true>("points, 12 B per lane, nt", buf, bytes, out);
     run_band<false>("nt, eight bands of 64 rows per block", buf, bytes, out);
     run_band<true>("nt, four bands of 128 rows, halves on adjacent rows", buf, bytes, out);
     for (int64_t seg : {65536ll, 262144ll, 1048576ll}) {
