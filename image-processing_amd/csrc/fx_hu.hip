@@ -1726,8 +1726,10 @@ int hu_batch_impl(const char *who, const HuScratch &scratch, const uint8_t *d_im
         A.bpw = 16;   // (gray weights, images up to 48 pixels wide: more rows per step would overflow the 32-bit partial sums)
     A.nbands = A.bpw * FX_WAVES_PER_BLOCK;
     A.hb = (H + A.nbands - 1) / A.nbands;
-    // every wave could meet all segments of its bands: cap per wave, four waves
-    const int64_t wave_segments = (int64_t)A.hb * A.bpw * A.cpr;
+    // every wave could meet a segment in every chunk it sees -- four loads of bpw rows per step of the sweep:
+    // cap per wave, four waves
+    const int64_t sweep_steps = (H + 16 * A.bpw - 1) / (16 * A.bpw);
+    const int64_t wave_segments = sweep_steps * 4 * A.bpw * A.cpr;
     A.qcap = (int)(wave_segments < 1024 ? wave_segments : 1024) * FX_WAVES_PER_BLOCK;
 
     // per-launch scratch: sums | queue counts | redo list
