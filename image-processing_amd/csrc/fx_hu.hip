@@ -1534,7 +1534,7 @@ inline int band_aligned(bool aligned, int W, int H, int64_t pitch_bytes, int hb)
 {
     if (!aligned || W % 16 != 0)
         return 0;
-    const int64_t rows = (H < 1024 ? H : 1024) + 512;  // a block sees a tile or an image of at most 1024 rows; bands may start below it
+    const int64_t rows = (H < 1024 ? H : 1024) + 1100;  // a block sees a tile or an image of at most 1024 rows; a step of the sweep may reach up to 1024 rows below it
     return hb < 64 && rows * pitch_bytes < (1ll << 31) ? 2 : 1;
 }
 
@@ -1749,6 +1749,9 @@ int hu_batch_impl(const char *who, const HuScratch &scratch, const uint8_t *d_im
         FX_HIP_CHECK(hipMemsetAsync(G.redo_count, 0, 16, s));
 
     A.wave_lds = contour && A.qcap > BAND_SLAB_BYTES ? A.qcap : BAND_SLAB_BYTES;  // qcap / 4 entries of 4 bytes
+    // the columns of row masks of the sweep with contours lie in the block sums' slabs (cpr * bpw <= 64: 6.2 KiB at most)
+    FX_REQUIRE(!contour || (int64_t)A.cpr * ((3 * 16 * A.bpw + 2) * 2) <= (int64_t)FX_WAVES_PER_BLOCK * BAND_CSLAB_BYTES,
+               "%s: internal: row-mask columns of %d x %d bytes exceed the slabs", who, A.cpr, (3 * 16 * A.bpw + 2) * 2);
     size_t band_lds = (size_t)band_lds_wave(contour) + (size_t)FX_WAVES_PER_BLOCK * A.wave_lds;
     // Blocks per CU follow from the LDS a block asks for: 31 KiB lets five in.  Bands of 64 rows and more
     // stream long enough that four blocks per CU keep the memory system busy, and measure 2 % faster than
