@@ -90,6 +90,48 @@ __global__ __launch_bounds__(256) void point_kernel(const u32x4 *buf, int64_t se
     if (acc == 0x12345678u)
         out[blockIdx.x] = acc;
 }
+// A point per lane read as 16 bytes at a 12-byte stride (the fourth word is the next point's first).
+template <bool NT>
+__global__ __launch_bounds__(256) void point16_kernel(const u32x4 *buf, int64_t seg_vec, int64_t n_seg, uint32_t *out)
+{
+    typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    uint32_t acc = 0;
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(buf + (int64_t)blockIdx.x * seg_vec);
+    const int64_t n_pts = seg_vec * 16 / 12 - 1;
+    for (int64_t i = threadIdx.x; i < n_pts; i += 256 * 16) {
+        u32x4u v[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int64_t j = i + 256 * k < n_pts ? i + 256 * k : i;
+            const u32x4u *q = reinterpret_cast<const u32x4u *>(p + 3 * j);
+            v[k] = NT ? __builtin_nontemporal_load(q) : *q;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            acc ^= v[k].x ^ v[k].y ^ v[k].z;
+    }
+    if (acc == 0x12345678u)
+        out[blockIdx.x] = acc;
+}
+template <bool NT>
+void run_point16(const char *name, const u32x4 *buf, int64_t bytes, uint32_t *out)
+{
+    const int64_t seg_bytes = 98304, seg_vec = seg_bytes / 16, n_seg = bytes / seg_bytes;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0), (void)hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; rep++) {
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL((point16_kernel<NT>), dim3((unsigned)n_seg), dim3(256), 0, 0, buf, seg_vec, n_seg, out);
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+        float ms;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (rep && ms < best)
+            best = ms;
+    }
+    printf("%-44s segment %5lld KB: %7.3f ms  %6.0f GB/s\n", name, (long long)(seg_bytes >> 10), best, n_seg * seg_bytes / best / 1e6);
+}
 template <bool V3, bool NT>
 void run_points(const char *name, const u32x4 *buf, int64_t bytes, uint32_t *out)
 {
@@ -212,6 +254,8 @@ int main(int argc, char **argv)
     run_points<false, true>("points, 3 x 16 B per thread, nt", buf, bytes, out);
     run_points<true, false>("points, 12 B per lane, plain", buf, bytes, out);
     run_points<true, true>("points, 12 B per lane, nt", buf, bytes, out);
+    run_point16<false>("points, 16 B per lane at 12 B stride, plain", buf, bytes, out);
+    run_point16<true>("points, 16 B per lane at 12 B stride, nt", buf, bytes, out);
     run_band<false>("nt, eight bands of 64 rows per block", buf, bytes, out);
     run_band<true>("nt, four bands of 128 rows, halves on adjacent rows", buf, bytes, out);
     for (int64_t seg : {65536ll, 262144ll, 1048576ll}) {
