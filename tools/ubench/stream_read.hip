@@ -113,6 +113,63 @@ __global__ __launch_bounds__(256) void point16_kernel(const u32x4 *buf, int64_t 
     if (acc == 0x12345678u)
         out[blockIdx.x] = acc;
 }
+// Sets of 12 KB read the way a set kernel with prefetch would: a wave brings its next set (or SETW words of it)
+// to LDS with loads that have no register destination (1 KB in one piece per instruction), takes the one that
+// has arrived out of LDS a point (12 bytes) per lane, and starts the next transfer into the same buffer.
+template <bool NT, int SETW, int OCC>
+__global__ __launch_bounds__(256, OCC) void glds_kernel(const u32x4 *buf, int64_t n_sets, uint32_t *out)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds[4][SETW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void glb_void;
+    uint32_t *mine = lds[wave];
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    auto issue = [&](int64_t set) {
+        const u32x4 *g = buf + set * (SETW / 4) + lane;
+#pragma unroll
+        for (int k = 0; k < SETW / 256; k++)
+            __builtin_amdgcn_global_load_lds((glb_void *)(g + 64 * k), (lds_void *)(mine + 256 * k), 16, 0, NT ? 2 : 0);
+    };
+    uint32_t acc = 0;
+    int64_t set = (int64_t)blockIdx.x * 4 + wave;
+    if (set < n_sets)
+        issue(set);
+    for (; set < n_sets; set += stride) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        u32x3 v[SETW / 192];
+#pragma unroll
+        for (int i = 0; i < SETW / 192; i++)
+            v[i] = *reinterpret_cast<const u32x3 *>(mine + 3 * (lane + 64 * i));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (set + stride < n_sets)
+            issue(set + stride);
+#pragma unroll
+        for (int i = 0; i < SETW / 192; i++)
+            acc ^= v[i].x ^ v[i].y ^ v[i].z;
+    }
+    if (acc == 0x12345678u)
+        out[blockIdx.x] = acc;
+}
+template <bool NT, int SETW, int OCC>
+void run_glds(const char *name, const u32x4 *buf, int64_t bytes, uint32_t *out, int cus)
+{
+    const int64_t n_sets = bytes / (SETW * 4);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0), (void)hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; rep++) {
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL((glds_kernel<NT, SETW, OCC>), dim3((unsigned)(cus * OCC)), dim3(256), 0, 0, buf, n_sets, out);
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+        float ms;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (rep && ms < best)
+            best = ms;
+    }
+    printf("%-44s  %2d KB per wave, %d blocks per CU: %7.3f ms  %6.0f GB/s\n", name, SETW * 4 / 1024, OCC, best, n_sets * SETW * 4 / best / 1e6);
+}
 template <bool NT>
 void run_point16(const char *name, const u32x4 *buf, int64_t bytes, uint32_t *out)
 {
@@ -256,6 +313,12 @@ int main(int argc, char **argv)
     run_points<true, true>("points, 12 B per lane, nt", buf, bytes, out);
     run_point16<false>("points, 16 B per lane at 12 B stride, plain", buf, bytes, out);
     run_point16<true>("points, 16 B per lane at 12 B stride, nt", buf, bytes, out);
+    run_glds<false, 3072, 3>("to LDS, plain", buf, bytes, out, cus);
+    run_glds<true, 3072, 3>("to LDS, nt", buf, bytes, out, cus);
+    run_glds<true, 1536, 4>("to LDS, nt", buf, bytes, out, cus);
+    run_glds<false, 1536, 4>("to LDS, plain", buf, bytes, out, cus);
+    run_glds<true, 1536, 6>("to LDS, nt", buf, bytes, out, cus);
+    run_glds<true, 768, 8>("to LDS, nt", buf, bytes, out, cus);
     run_band<false>("nt, eight bands of 64 rows per block", buf, bytes, out);
     run_band<true>("nt, four bands of 128 rows, halves on adjacent rows", buf, bytes, out);
     for (int64_t seg : {65536ll, 262144ll, 1048576ll}) {
