@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--dir", default=None)
     ap.add_argument("--batch_samples", type=int, default=256)
     ap.add_argument("--repeats", type=int, default=3)
+    ap.add_argument("--profile_pca", action="store_true", help="cProfile listing of the point-set driver's run")
     ap.add_argument("--kind", default="rendered", choices=["rendered", "noisy"],
                     help="views: renderings of synthetic clouds (what the reference's run reads: dark markers on white, "
                          "a few KB per PNG) or noisy gray shapes (the worst case for the inflate: 35 KB per PNG)")
@@ -122,9 +123,16 @@ def main():
         ing.map_ordered(hu.load_image, files, a.workers)
         out["pil_threads_decode_only_views_per_s"] = n_img / (time.perf_counter() - t0)
 
+        pca_argv = ["--sampled_dir", str(sampled), "--out_dir", str(root / "desc"), "--reports_dir",
+                    str(root / "rep"), "--overwrite", "--workers", str(a.workers)]
+        if a.profile_pca:
+            import cProfile
+            import pstats
+            prof = cProfile.Profile()
+            prof.runcall(pca.main, pca_argv)
+            pstats.Stats(prof).sort_stats("cumulative").print_stats(35)
         t0 = time.perf_counter()
-        rc = pca.main(["--sampled_dir", str(sampled), "--out_dir", str(root / "desc"), "--reports_dir",
-                       str(root / "rep"), "--overwrite", "--workers", str(a.workers)])
+        rc = pca.main(pca_argv)
         t_pca = time.perf_counter() - t0
         assert rc == 0
         out["pca_seconds"] = t_pca
