@@ -273,8 +273,22 @@ def process_file(args_tuple):
 
 def records_to_frame(records: List[dict], n_bins: int):
     """DataFrame with the exact column order of descriptors_table_pca.csv
-    (reference :383-414)."""
+    (reference :383-414).  Records of sets that went through (every base
+    column present and set) are laid out column by column; anything else is
+    built row by row as the reference does -- same frame either way."""
     import pandas as pd
+    cols = column_names(n_bins)
+    if records and all(rec.get("n_points") is not None and all(c in rec for c in BASE_COLS) for rec in records):
+        data = {c: [rec[c] for rec in records] for c in BASE_COLS}
+        hists = []
+        for rec in records:
+            hist = rec.get("proj_hist") or [0.0] * n_bins
+            if len(hist) != n_bins:
+                hist = (list(hist) + [0.0] * max(0, n_bins - len(hist)))[:n_bins]
+            hists.append(hist)
+        for i in range(n_bins):
+            data[f"proj_hist_bin_{i}"] = [float(h[i]) for h in hists]
+        return pd.DataFrame(data, columns=cols)
     rows = []
     for rec in records:
         row = {c: rec.get(c, np.nan) for c in BASE_COLS}
@@ -285,13 +299,11 @@ def records_to_frame(records: List[dict], n_bins: int):
         for i in range(n_bins):
             row[f"proj_hist_bin_{i}"] = float(hist[i])
         rows.append(row)
-    return pd.DataFrame(rows, columns=column_names(n_bins))
+    return pd.DataFrame(rows, columns=cols)
 
 
-def list_npy_files(root: Path) -> List[Path]:
-    """What sorted(p for p in root.rglob("*.npy") if p.is_file()) gives, ordered by str(path) (reference
-    :312-316), from os.scandir: directories that are symbolic links are not entered, links to files count as
-    files, a directory that may not be read is skipped.  (pathlib takes 7 us per file for the same list.)"""
+def list_npy_paths(root) -> List[str]:
+    """The .npy files below `root` as strings, in the order of list_npy_files."""
     found: List[str] = []
     stack = [str(root)]
     while stack:
@@ -310,7 +322,16 @@ def list_npy_files(root: Path) -> List[Path]:
                     found.append(e.path)
             except OSError:
                 continue
-    return [Path(p) for p in sorted(found)]
+    found.sort()
+    return found
+
+
+def list_npy_files(root: Path) -> List[Path]:
+    """What sorted(p for p in root.rglob("*.npy") if p.is_file()) gives, ordered by str(path) (reference
+    :312-316), from os.scandir: directories that are symbolic links are not entered, links to files count as
+    files, a directory that may not be read is skipped.  (pathlib takes 7 us per file for the same list; main()
+    works on list_npy_paths, the strings, and saves the 4 us per file that a Path object costs.)"""
+    return [Path(p) for p in list_npy_paths(root)]
 
 
 def parse_args(argv=None):
@@ -349,14 +370,16 @@ def main(argv=None) -> int:
     if not sampled_dir.exists():
         logger.error(f"Sampled directory not found: {sampled_dir}")
         return 2
-    files = list_npy_files(sampled_dir)
+    files = list_npy_paths(sampled_dir)      # str(p) of list_npy_files' entries, without the Path objects
+    if str(sampled_dir) == ".":               # (pathlib drops the "./" that os.scandir(".") puts in front)
+        files = [f[2:] for f in files]
     limit = 20 if args.fast else args.max_samples
     if limit is not None:
         files = files[:limit]
     if not files:
         logger.warning("No .npy files found; exiting.")
         return 0
-    tasks = [(str(p), str(sampled_dir), str(out_dir), int(args.n_bins), bool(args.normalize), bool(args.overwrite),
+    tasks = [(p, str(sampled_dir), str(out_dir), int(args.n_bins), bool(args.normalize), bool(args.overwrite),
               manifest_map, str(reports_dir)) for p in files]
     from . import ingest
     workers = int(args.workers) if args.workers else None

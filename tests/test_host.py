@@ -490,3 +490,49 @@ def test_npy_listing_equals_pathlib(tmp_path):
     want = sorted((p for p in root.rglob("*.npy") if p.is_file()), key=lambda p: str(p))
     assert pca.list_npy_files(root) == want
     assert len(want) == 6
+    assert pca.list_npy_paths(root) == [str(p) for p in want]      # what main() works on
+
+
+def test_records_to_frame_columnar_equals_row_by_row():
+    """Records of sets that went through are laid out by column; the frame and its CSV text must be the ones the
+    row-by-row construction (the reference's, extract_3d_pca_features.py:383-414) gives, short and long
+    histograms included; a record with a gap takes the row-by-row route."""
+    import io
+    import pandas as pd
+    pca = pkg("extract_3d_pca_features")
+    rng = np.random.default_rng(3)
+    keys = ["lambda1", "lambda2", "lambda3", "r1", "r2", "r3", "ratio12", "ratio23", "trace"]
+
+    def row_by_row(records, n_bins):
+        rows = []
+        for rec in records:
+            row = {c: rec.get(c, np.nan) for c in pca.BASE_COLS}
+            row["id"] = rec.get("id", "")
+            row["raw_path"] = rec.get("raw_path", "")
+            hist = rec.get("proj_hist") or [0.0] * n_bins
+            hist = list(hist) + [0.0] * max(0, n_bins - len(hist))
+            for i in range(n_bins):
+                row[f"proj_hist_bin_{i}"] = float(hist[i])
+            rows.append(row)
+        return pd.DataFrame(rows, columns=pca.column_names(n_bins))
+
+    recs = []
+    for k in range(50):
+        vec = rng.random(9 + 8).astype(np.float32).astype(np.float64).tolist()
+        rec = {"id": f"tree_{k:03d}", "raw_path": "" if k % 3 else f"/raw/tree_{k:03d}.ply", "n_points": 1024 + k,
+               "proj_hist": vec[9:], "descriptor_path": f"/d/pca_tree_{k:03d}.npy"}
+        rec.update(zip(keys, vec[:9]))
+        recs.append(rec)
+    recs[4]["proj_hist"] = recs[4]["proj_hist"][:5]          # shorter than n_bins: padded with zeros
+    recs[5]["proj_hist"] = recs[5]["proj_hist"] + [0.5, 0.25]  # longer: cut
+    recs[6]["proj_hist"] = None
+    for n_bins in (8, 6):
+        got, want = pca.records_to_frame(recs, n_bins), row_by_row(recs, n_bins)
+        pd.testing.assert_frame_equal(got, want)
+        a, b = io.StringIO(), io.StringIO()
+        got.to_csv(a, index=False)
+        want.to_csv(b, index=False)
+        assert a.getvalue() == b.getvalue()
+    holed = recs[:3] + [{"id": "bad", "raw_path": "", "n_points": None, "proj_hist": None}]
+    pd.testing.assert_frame_equal(pca.records_to_frame(holed, 8), row_by_row(holed, 8))
+    pd.testing.assert_frame_equal(pca.records_to_frame([], 8), row_by_row([], 8))

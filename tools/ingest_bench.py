@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--dir", default=None)
     ap.add_argument("--batch_samples", type=int, default=256)
     ap.add_argument("--repeats", type=int, default=3)
+    ap.add_argument("--batch_files", type=int, default=None, help="point-set files per device batch (default: the driver's)")
     ap.add_argument("--profile_pca", action="store_true", help="cProfile listing of the point-set driver's run")
     ap.add_argument("--kind", default="rendered", choices=["rendered", "noisy"],
                     help="views: renderings of synthetic clouds (what the reference's run reads: dark markers on white, "
@@ -125,17 +126,23 @@ def main():
 
         pca_argv = ["--sampled_dir", str(sampled), "--out_dir", str(root / "desc"), "--reports_dir",
                     str(root / "rep"), "--overwrite", "--workers", str(a.workers)]
+        if a.batch_files:
+            pca_argv += ["--batch_files", str(a.batch_files)]
         if a.profile_pca:
             import cProfile
             import pstats
             prof = cProfile.Profile()
             prof.runcall(pca.main, pca_argv)
             pstats.Stats(prof).sort_stats("cumulative").print_stats(35)
-        t0 = time.perf_counter()
-        rc = pca.main(pca_argv)
-        t_pca = time.perf_counter() - t0
-        assert rc == 0
+        runs = []
+        for _ in range(a.repeats):
+            t0 = time.perf_counter()
+            rc = pca.main(pca_argv)
+            runs.append(time.perf_counter() - t0)
+            assert rc == 0
+        t_pca = min(runs)
         out["pca_seconds"] = t_pca
+        out["pca_seconds_runs"] = runs
         out["clouds_per_s"] = a.clouds / t_pca
         print(json.dumps(out), flush=True)
     finally:
