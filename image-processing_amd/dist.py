@@ -15,6 +15,15 @@ import torch
 import torch.distributed as dist
 
 
+# A process group of fewer ranks than this has nothing to exchange and the helpers below hand their input back.
+# (A test on one GPU sets it to 1, so that the very collective calls of the N-rank case run on the RCCL backend.)
+MIN_RANKS_FOR_COLLECTIVES = 2
+
+
+def _exchanging() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() >= MIN_RANKS_FOR_COLLECTIVES
+
+
 def shard_range(n_units: int, rank: int, world: int) -> Tuple[int, int]:
     """[lo, hi) of rank's contiguous block: ceil(n/world) units per rank, the
     last ranks may get fewer (or none)."""
@@ -44,7 +53,7 @@ def all_gather_rows(local: torch.Tensor, n_units: int) -> torch.Tensor:
     """Gathers the per-rank [rows_r, F] blocks of a contiguous sharding of
     n_units rows into the [n_units, F] table on every rank.  Without an
     initialised process group (single process) returns `local`."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _exchanging():
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
     per = -(-n_units // world)
@@ -78,7 +87,7 @@ def all_gather_tagged_rows(rows: torch.Tensor, ids: Sequence[int], slot: int, n_
     if k:
         block[:k, 0] = torch.as_tensor(list(ids), dtype=rows.dtype, device=rows.device)
         block[:k, 1:] = rows
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _exchanging():
         gathered = torch.empty((dist.get_world_size() * slot, F + 1), dtype=rows.dtype, device=rows.device)
         dist.all_gather_into_tensor(gathered, block)
     else:
@@ -98,7 +107,7 @@ def describe_ranks(step_ms: float, device_name: str) -> dict:
     """What a reader needs to confirm that a multi-process run was one: the size
     of the process group as the backend reports it, every rank's device, and the
     spread of the ranks' own step times."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _exchanging():
         return {"ranks": 1, "backend": None, "devices": [device_name],
                 "ms_per_step_rank_min": step_ms, "ms_per_step_rank_max": step_ms}
     world = dist.get_world_size()
@@ -142,7 +151,7 @@ def all_reduce_partial(partial: torch.Tensor) -> torch.Tensor:
     initialised process group returns `partial` unchanged."""
     if partial.dtype != torch.int64 or partial.dim() != 3 or tuple(partial.shape[1:]) != (10, 3):
         raise ValueError("partial must be int64 [B, 10, 3]")
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _exchanging():
         if dist.get_world_size() > (1 << 15):
             raise ValueError("limb sums are exact for up to 2^15 ranks")
         dist.all_reduce(partial, op=dist.ReduceOp.SUM)
@@ -175,7 +184,7 @@ class GatherPipeline:
         self.depth = max(1, int(depth))
         self.pending: List[tuple] = []
         self.last = None
-        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.active = _exchanging()
 
     def submit(self, block: torch.Tensor) -> None:
         if not self.active:

@@ -216,6 +216,51 @@ def test_allgather_features_on_a_one_rank_communicator(gpu):
         rccl.ncclCommDestroy(comm)
 
 
+def test_exchange_helpers_on_a_one_rank_rccl_group(gpu, monkeypatch):
+    """The collectives of the N-rank run -- the feature all-gather (blocking, and two deep through GatherPipeline), the
+    id-tagged gather of units assigned by cost, the limb all-reduce of row bands and the description of the ranks --
+    issued on torch.distributed's RCCL backend with a group of one rank: same calls, same tensors, one participant.
+    (What several ranks add is covered over gloo on the CPU.)"""
+    import socket
+    import torch
+    import torch.distributed as td
+    fxdist = pkg("dist")
+    eng = pkg("engine")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    assert not td.is_initialized()
+    td.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=gpu)
+    try:
+        monkeypatch.setattr(fxdist, "MIN_RANKS_FOR_COLLECTIVES", 1)
+        imgs = eng.synth_shapes(37, 64, 64, seed=5, device=gpu)
+        feats = eng.hu_batch(imgs, thresh=127, on_value=255)["hulog7"]
+        table = fxdist.all_gather_rows(feats, 37)
+        assert table.data_ptr() != feats.data_ptr() and torch.equal(table, feats)
+        pipe = fxdist.GatherPipeline(depth=2)
+        assert pipe.active
+        blocks = []
+        for k in range(5):
+            blocks.append(eng.hu_batch(imgs[k:k + 20], thresh=127, on_value=255)["hulog7"])
+            pipe.submit(blocks[-1])
+        assert torch.equal(pipe.drain(), blocks[-1])
+        rows = torch.arange(6 * 17, dtype=torch.float32, device=gpu).reshape(6, 17)
+        order = [4, 0, 5, 2, 1, 3]
+        tagged = fxdist.all_gather_tagged_rows(rows, order, 8, 6)
+        assert torch.equal(tagged[order], rows)
+        with pytest.raises(ValueError, match="missing"):
+            fxdist.all_gather_tagged_rows(rows[:5], order[:5], 8, 6)
+        tall = eng.synth_shapes(2, 1024, 512, seed=9, device=gpu)
+        whole = eng.hu_batch(tall, thresh=127, on_value=255)["hulog7"]
+        banded = fxdist.hu_rowbands(tall, 0, 127, 255)["hulog7"]
+        assert torch.equal(banded, whole)
+        report = fxdist.describe_ranks(1.25, torch.cuda.get_device_name(gpu))
+        assert report["ranks"] == 1 and report["backend"] == "nccl" and len(report["devices"]) == 1
+        torch.cuda.synchronize()
+    finally:
+        td.destroy_process_group()
+
+
 def test_clouds_to_hu_table_on_the_device(gpu, oracle, c_oracle, tmp_path):
     """Clouds -> rendered views -> preprocessing -> Hu -> per-sample statistics
     without leaving HBM equals the chain through PNG files: the oracle's
