@@ -181,8 +181,10 @@ __global__ __launch_bounds__(FX_WAVE) void png_inflate_kernel(PngArgs A)
     const int lane = fx_lane();
     const int64_t f = blockIdx.x;
     const uint32_t *z = reinterpret_cast<const uint32_t *>(A.staged + A.offset[f]);
-    const int zlen = A.length[f];
-    const uint32_t zwords = (uint32_t)((zlen + 3) >> 2) + 4u;   // (the host left 16 zero bytes behind the stream)
+    const int ch_f = A.channels[f];
+    const bool listed = A.length[f] >= 6 && ch_f >= 1 && ch_f <= A.max_ch;   // (else: a header status, and not a byte of the stream is read)
+    const int zlen = listed ? A.length[f] : 0;
+    const uint32_t zwords = listed ? (uint32_t)((zlen + 3) >> 2) + 4u : 0u;   // (the host left 16 zero bytes behind the stream)
     uint8_t *out = A.raw + A.raw_offset[f];   // (written and, for matches, read back by lane 0 alone)
     const int64_t want = A.raw_offset[f + 1] - A.raw_offset[f];
 
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(FX_WAVE) void png_inflate_kernel(PngArgs A)
         // zlib wrapper: deflate, window <= 32 KiB, no preset dictionary, header check
         br.fill();
         const uint32_t cmf = br.take(8), flg = br.take(8);
-        if ((cmf & 15u) != 8u || (cmf >> 4) > 7u || (flg & 32u) || ((cmf << 8) | flg) % 31u != 0u || zlen < 6)
+        if ((cmf & 15u) != 8u || (cmf >> 4) > 7u || (flg & 32u) || ((cmf << 8) | flg) % 31u != 0u || !listed)
             status = PNG_EHEADER;
     }
 
@@ -490,6 +492,8 @@ __global__ __launch_bounds__(FX_WAVE) void png_unfilter_kernel(PngArgs A)
     if (A.status[f] != PNG_OK)
         return;
     const int ch = A.channels[f];
+    if (ch < 1 || ch > A.max_ch)   // (the inflate kernel has given such a file a header status; the rows in LDS hold max_ch channels)
+        return;
     const int stride = A.W * ch;
     const uint8_t *raw = A.raw + A.raw_offset[f];
     uint8_t *out = A.out + f * (int64_t)A.H * A.W;

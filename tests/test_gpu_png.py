@@ -164,6 +164,31 @@ def test_what_the_device_does_not_decode_gets_a_status(gpu, tmp_path):
         np.testing.assert_array_equal(gray[i], good)
 
 
+def test_entries_a_caller_filled_in_wrongly_get_a_status(gpu, tmp_path):
+    """The device entry point takes the three per-file arrays from its caller: a channel count outside 1 .. 4 (or more
+    than a row of 4096 bytes holds), a negative length and a length below the six bytes of the smallest zlib stream
+    end with a status without a byte of the stream being read; the files around them decode as ever."""
+    rng = np.random.default_rng(21)
+    H, W = 32, 48
+    good = view_like(rng, H, W)
+    paths = [tmp_path / f"g{k}.png" for k in range(7)]
+    for k, p in enumerate(paths):
+        write_png(p, good, [k % 5])
+    ingest, eng = pkg("ingest"), pkg("engine")
+    staged = ingest.stage_png_batch([str(p) for p in paths], H, W, 2)
+    assert (staged["status"] == 0).all()
+    staged["channels"][1] = 0
+    staged["channels"][2] = 9
+    staged["channels"][3] = -3
+    staged["length"][4] = -1000
+    staged["length"][5] = 5
+    got = eng.png_inflate_batch(staged, H, W, gpu)
+    status, gray = got["status"].cpu().numpy(), got["gray"].cpu().numpy()
+    assert status[0] == 0 and status[6] == 0 and (status[1:6] != 0).all()
+    np.testing.assert_array_equal(gray[0], good)
+    np.testing.assert_array_equal(gray[6], good)
+
+
 def test_many_files_in_one_call(gpu, tmp_path):
     """A few thousand views in one launch, against the host decoder (which equals PIL, tests/test_host.py)."""
     from PIL import Image
