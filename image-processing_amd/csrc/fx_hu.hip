@@ -1722,8 +1722,10 @@ int hu_batch_impl(const char *who, const HuScratch &scratch, const uint8_t *d_im
     }
 
     A.bpw = FX_WAVE / A.cpr;
-    if (!contour && mode == MODE_GRAY && A.bpw > 16)
-        A.bpw = 16;   // (gray weights, images up to 48 pixels wide: more rows per step would overflow the 32-bit partial sums)
+    if (mode == MODE_GRAY && A.bpw > 16)
+        A.bpw = 16;   // (gray weights, images up to 48 pixels wide: a lane's four rows of a step lie bpw rows apart, and with
+                      // more than 21 the cube of the row offset times a chunk's 16 * 255 overflows the 32-bit partial sums --
+                      // with or without the contour descriptor)
     A.nbands = A.bpw * FX_WAVES_PER_BLOCK;
     A.hb = (H + A.nbands - 1) / A.nbands;
     // every wave could meet a segment in every chunk it sees -- four loads of bpw rows per step of the sweep:

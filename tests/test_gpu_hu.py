@@ -223,6 +223,31 @@ def test_ragged_masks_overflow_path(gpu, oracle, c_oracle):
         assert (np.abs(got["cpca"][b, 9:].astype(np.float64) - ref[9:]) * n).max() <= 2.5
 
 
+@pytest.mark.parametrize("size", [(224, 16), (224, 22), (224, 32), (512, 20), (1024, 8), (1000, 47)])
+def test_gray_weights_on_narrow_images_with_contours(gpu, c_oracle, size):
+    """Gray weights, images of one or two 16-pixel chunks per row, all pixels 255: the largest partial sums the
+    sweep forms.  With the contour descriptor switched on the rows of a lane lay 32 or 64 apart and the 32-bit sum
+    of (row offset)^3 * weights overflowed; the moments must be the oracle's with and without it."""
+    H, W = size
+    rng = np.random.default_rng(5)
+    imgs = np.concatenate([np.full((2, H, W), 255, np.uint8), rng.integers(0, 256, (2, H, W), dtype=np.uint8)])
+    ref = c_oracle.hu_batch(imgs, thresh=-1, exact=True)
+    for nb in (None, 8):
+        check_against_oracle(run_gpu(gpu, imgs, thresh=-1, contour_bins=nb), ref)
+
+
+def test_random_geometry_against_oracle(gpu, c_oracle):
+    """tools/hufuzz.py's cases (sizes from 1 x 1 to beyond the tile size, widths next to multiples of 16, padded
+    rows, unaligned bases, the three weight modes, mixed content, with and without contours), a fixed seed."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tools"))
+    import hufuzz
+    rng = np.random.default_rng(20261112)
+    for _ in range(120):
+        hufuzz.run_case(rng, gpu, c_oracle)
+
+
 def test_full_size_properties(gpu):
     """C2/C3-sized batches: properties that need no CPU pass over the data.
     Raw moments are additive over disjoint masks and the Hu vector is invariant
