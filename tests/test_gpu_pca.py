@@ -421,3 +421,16 @@ def test_non_finite_points_do_not_disturb_their_neighbours(gpu, oracle, N):
             assert not np.isfinite(out[b]).all()
         else:
             np.testing.assert_array_equal(out[b], clean[b])
+
+
+def test_random_batch_geometry_against_oracle(gpu):
+    """tools/pcafuzz.py's cases (equal-size and CSR batches, sets from none to tens of thousands of points in one call,
+    2-D / 3-D, float32 / float64, 1 .. 64 bins, both normalize settings, identical and collinear points), a fixed
+    seed."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tools"))
+    import pcafuzz
+    rng = np.random.default_rng(20261112)
+    for _ in range(80):
+        pcafuzz.run_case(rng, gpu)
