@@ -2208,6 +2208,40 @@ __global__ __launch_bounds__(FX_BLOCK) void gray_fit_kernel(FitArgs A)
         __syncthreads();
 
         const uint8_t *src = A.img + b * A.stride + (int64_t)y0 * A.pitch + x0;
+        // Image.resize reduces an image that is more than a hundred times as tall as it is wide along y first and
+        // along x afterwards (PIL/Image.py, "self.size[1] > self.size[0] * 100 and size[1] < self.size[1]"): the
+        // uint8 rounding between the passes makes the order visible.  Such a crop is at most five pixels wide here;
+        // a pixel and a tap at a time will do.
+        if (horiz && vert && ch > 100 * cw && nh < ch) {
+            for (int i = t; i < nh * cw; i += FX_BLOCK) {   // pass along y: temp[yy][x], nh rows of cw pixels
+                const int yy = i / cw, x = i - yy * cw;
+                const int32_t *k = s_ky + yy * kys;
+                const int n = s_ycnt[yy], lo = s_ylo[yy];
+                int acc = 1 << (FIT_PRECISION_BITS - 1);
+                for (int j = 0; j < n; j++)
+                    acc += __mul24((int)src[(int64_t)(lo + j) * A.pitch + x], k[j]);
+                temp[i] = fit_clip8(acc);
+            }
+            __threadfence_block();
+            __syncthreads();
+            const int qx0 = (res - nw) / 2, qy0 = (res - nh) / 2;
+            uint8_t *o = A.out + b * (int64_t)res * res;
+            for (int i = t; i < res * res; i += FX_BLOCK) {   // pass along x and paste
+                const int Y = i / res, X = i - Y * res;
+                const int yy = Y - qy0, xx = X - qx0;
+                int v = A.bg;
+                if (yy >= 0 && yy < nh && xx >= 0 && xx < nw) {
+                    const int32_t *k = s_kx + xx * kxs;
+                    const int n = s_xcnt[xx], lo = s_xlo[xx];
+                    int acc = 1 << (FIT_PRECISION_BITS - 1);
+                    for (int j = 0; j < n; j++)
+                        acc += __mul24((int)temp[yy * cw + lo + j], k[j]);
+                    v = fit_clip8(acc);
+                }
+                o[i] = (uint8_t)v;
+            }
+            continue;
+        }
         // pass along x: temp[y][xx], ch rows of nw pixels
         // The common case (no reduction: five taps per axis) takes FIT_UNROLL pixels
         // per thread and step with every load issued before the first use: one

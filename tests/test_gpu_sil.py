@@ -304,6 +304,18 @@ def test_gray_fit_equals_pil(gpu, oracle, h, w, res):
                                       err_msg=f"rect {k}")
 
 
+@pytest.mark.parametrize("h,w,res", [(482, 3, 189), (482, 4, 189), (301, 3, 224), (300, 3, 224), (512, 5, 100), (512, 2, 500)])
+def test_gray_fit_of_very_tall_crops(gpu, oracle, h, w, res):
+    """Pillow's Image.resize reduces an image more than a hundred times as tall as wide along y first and along x
+    afterwards, any other along x first; the uint8 rounding between the passes shows which (300 x 3 is the last size
+    that goes along x first)."""
+    rng = np.random.default_rng(h + w)
+    imgs = rng.integers(0, 256, (3, h, w), dtype=np.uint8)
+    got = fit(gpu, imgs, None, res, 255)
+    for k in range(len(imgs)):
+        np.testing.assert_array_equal(got[k], oracle.pad_and_resize(imgs[k], res, "white"), err_msg=f"image {k}")
+
+
 def test_preprocess_image_signature(gpu, oracle, hu_panels):
     hu = pkg("extract_2d_hu")
     img = hu_panels["raw_views"][3, 1]
