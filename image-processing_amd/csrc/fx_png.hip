@@ -225,11 +225,15 @@ __global__ __launch_bounds__(FX_WAVE) void png_inflate_kernel(PngArgs A)
             status = PNG_EHEADER;
     }
 
-    // (every round of this loop uses up bits of the stream, ten at the very least: the bound is never reached by a
-    // stream that decodes, and ends the wave whatever the bytes are)
-    for (int round = 0;; round++) {
+    // (Every round of this loop uses up bits of the stream, or follows one that did -- the round that builds a
+    // block's tables.  A long match takes a round of its own and may cost two bits, one for a length code and one
+    // for a distance code that are each the only one of their kind: a flat image of a megabyte is a few thousand
+    // such matches in a few hundred bytes.  Two rounds per bit is a bound no stream that decodes can reach, and it
+    // ends the wave whatever the bytes are.)
+    const long long max_rounds = 16ll * (long long)zlen + 64;
+    for (long long round = 0;; round++) {
         // ---- every lane: state from lane 0, the ring kept at least half full ahead of the reader
-        if (round > zlen + 64)
+        if (round > max_rounds)
             status = PNG_EINPUT;
         status = __builtin_amdgcn_readfirstlane(status);
         phase = __builtin_amdgcn_readfirstlane(phase);

@@ -207,3 +207,33 @@ def test_many_files_in_one_call(gpu, tmp_path):
     st, _ = pkg("ingest").decode_png_batch([str(p) for p in many], H, W, host, 8)
     assert (st == 0).all()
     np.testing.assert_array_equal(gray, host)
+
+
+def test_streams_of_a_few_bits_per_match(gpu, tmp_path):
+    """Flat and periodic images of hundreds of kilobytes deflate to a few hundred bytes: thousands of maximal
+    matches at two or three bits each, far more decoding rounds than stream bytes.  The device decodes them."""
+    from PIL import Image
+    H, W = 281, 711
+    flat = np.full((H, W, 4), 200, dtype=np.uint8)
+    period = np.resize(np.arange(7, dtype=np.uint8) * 30, (H, W, 3)).copy()
+    paths = [tmp_path / "flat.png", tmp_path / "period.png", tmp_path / "flat9.png"]
+    write_png(paths[0], flat, [0], level=9)
+    write_png(paths[1], period, [0, 2], level=6)
+    Image.fromarray(flat[:, :, 0]).save(paths[2], compress_level=9)
+    assert all(p.stat().st_size < 4000 for p in paths)
+    staged, rows, gray, status = decode_on_device(paths, H, W, gpu)
+    assert (staged["status"] == 0).all() and (status == 0).all(), (staged["status"], status)
+    for i, p in enumerate(paths):
+        np.testing.assert_array_equal(gray[i], np.asarray(Image.open(p).convert("L")), err_msg=p.name)
+
+
+def test_random_files_against_pil(gpu, tmp_path):
+    """tools/pngfuzz.py's batches (random sizes, channels, filters, zlib levels, strategies and windows, IDAT splits,
+    damaged streams), a fixed seed."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tools"))
+    import pngfuzz
+    rng = np.random.default_rng(20261112)
+    for _ in range(20):
+        pngfuzz.run_batch(rng, gpu, tmp_path)
