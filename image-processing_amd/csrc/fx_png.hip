@@ -182,7 +182,11 @@ __global__ __launch_bounds__(FX_WAVE) void png_inflate_kernel(PngArgs A)
     const int64_t f = blockIdx.x;
     const uint32_t *z = reinterpret_cast<const uint32_t *>(A.staged + A.offset[f]);
     const int ch_f = A.channels[f];
-    const bool listed = A.length[f] >= 6 && ch_f >= 1 && ch_f <= A.max_ch;   // (else: a header status, and not a byte of the stream is read)
+    // (else: a header status, and not a byte of the stream is read.  Deflate grows incompressible data by a few bytes
+    // per 64 KiB; a stream of more than twice the bytes it is to produce is left to the host decoder, which also
+    // bounds the time a wave can spend on bytes made up to keep it busy.)
+    const int64_t raw_bytes = A.raw_offset[f + 1] - A.raw_offset[f];
+    const bool listed = A.length[f] >= 6 && ch_f >= 1 && ch_f <= A.max_ch && (int64_t)A.length[f] <= 2 * raw_bytes + 1024;
     const int zlen = listed ? A.length[f] : 0;
     const uint32_t zwords = listed ? (uint32_t)((zlen + 3) >> 2) + 4u : 0u;   // (the host left 16 zero bytes behind the stream)
     uint8_t *out = A.raw + A.raw_offset[f];   // (written and, for matches, read back by lane 0 alone)

@@ -388,8 +388,9 @@ int fx_decode_png_gray_u8(const char *const *paths, int64_t n, int H, int W,
  * bytes with a matching Adler-32 (damaged data, a preset dictionary, a
  * filter type above 4): such a file is the caller's to hand to the host
  * decoder or PIL, like any other status.  W * channels <= 4096.  An entry
- * whose channel count is not 1 .. 4 (or does not fit such a row) or whose
- * length is below 6 gets a status too, and its stream is not read.
+ * whose channel count is not 1 .. 4 (or does not fit such a row), whose
+ * length is below 6 or above twice the bytes it is to produce + 1024 gets a
+ * status too, and its stream is not read.
  */
 int64_t fx_png_stage_bytes(const char *const *paths, int64_t n, int n_threads);
 int fx_png_stage(const char *const *paths, int64_t n, int H, int W, uint8_t *staging, int64_t capacity,

@@ -182,6 +182,7 @@ def test_entries_a_caller_filled_in_wrongly_get_a_status(gpu, tmp_path):
     staged["channels"][3] = -3
     staged["length"][4] = -1000
     staged["length"][5] = 5
+    # (a stream of more than twice the bytes it is to produce is declined as well: the stage arrays are given room for it)
     got = eng.png_inflate_batch(staged, H, W, gpu)
     status, gray = got["status"].cpu().numpy(), got["gray"].cpu().numpy()
     assert status[0] == 0 and status[6] == 0 and (status[1:6] != 0).all()
