@@ -91,8 +91,9 @@ def run_case(rng, dev, c_oracle, verbose=False):
     big = torch.zeros((B, H + extra, W + pad + off), dtype=torch.uint8, device=dev)
     view = big[:, :H, off:off + W]
     view.copy_(torch.from_numpy(imgs).to(dev))
-    tag = f"B={B} {H}x{W} pad={pad} off={off} extra={extra} thresh={thresh} on={on} bins={nb}"
-    res = eng.hu_batch(view, thresh=thresh, on_value=on, moments=True, hu=True, contour_bins=nb, contour_eig=contour)
+    noalloc = bool(rng.integers(0, 4) == 0)   # the entry point that allocates nothing: same kernels, scratch in a built-in block
+    tag = f"B={B} {H}x{W} pad={pad} off={off} extra={extra} thresh={thresh} on={on} bins={nb}" + (" noalloc" if noalloc else "")
+    res = eng.hu_batch(view, thresh=thresh, on_value=on, moments=True, hu=True, contour_bins=nb, contour_eig=contour, noalloc=noalloc)
     torch.cuda.synchronize()
     got = {k: v.cpu().numpy() for k, v in res.items()}
     ref = c_oracle.hu_batch(imgs, thresh=thresh, on_value=on, exact=max(H, W) > 512)
