@@ -54,55 +54,62 @@ int parse_npy_header(const unsigned char *buf, size_t len, NpyHeader *h)
         return FX_IO_EFORMAT;
     const char *t = (const char *)buf + off;
     const std::string_view text(t, hlen);
-    auto find_after = [&](const char *key) -> size_t {
-        const size_t p = text.find(key);
-        return p == std::string_view::npos ? p : p + strlen(key);
+    // Only the header numpy.save writes is taken, character for character:
+    //   {'descr': '<f4', 'fortran_order': False, 'shape': (R, C), } + spaces + '\n'
+    // A header in any other form (another writer's key order or spacing, or damaged bytes that np.load would refuse)
+    // leaves the file to np.load, which then decides as the reference's loader does.
+    size_t p = 0;
+    auto lit = [&](const char *s) -> bool {
+        const size_t n = strlen(s);
+        if (text.substr(p, n) != std::string_view(s, n))
+            return false;
+        p += n;
+        return true;
     };
-    size_t p = find_after("'descr':");
-    if (p == std::string_view::npos)
+    auto number = [&](int64_t *v) -> bool {
+        if (p >= hlen || text[p] < '0' || text[p] > '9' || (text[p] == '0' && p + 1 < hlen && text[p + 1] >= '0' && text[p + 1] <= '9'))
+            return false;
+        int64_t x = 0;
+        int digits = 0;
+        while (p < hlen && text[p] >= '0' && text[p] <= '9') {
+            if (++digits > 15)
+                return false;
+            x = x * 10 + (text[p++] - '0');
+        }
+        *v = x;
+        return true;
+    };
+    if (!lit("{'descr': '"))
         return FX_IO_EFORMAT;
-    while (p < hlen && (text[p] == ' '))
-        p++;
-    if (p + 5 > hlen || (text[p] != '\'' && text[p] != '"'))
-        return FX_IO_EDTYPE;
-    const std::string_view descr = text.substr(p + 1, 3);
-    if (descr == "<f4")
+    if (lit("<f4"))
         h->itemsize = 4;
-    else if (descr == "<f8")
+    else if (lit("<f8"))
         h->itemsize = 8;
     else
         return FX_IO_EDTYPE;
-    p = find_after("'fortran_order':");
-    if (p == std::string_view::npos)
+    if (!lit("', 'fortran_order': "))
         return FX_IO_EFORMAT;
-    while (p < hlen && text[p] == ' ')
-        p++;
-    if (text.substr(p, 5) != "False")
+    if (lit("True"))
         return FX_IO_EDTYPE;
-    p = find_after("'shape':");
-    if (p == std::string_view::npos)
+    if (!lit("False, 'shape': ("))
         return FX_IO_EFORMAT;
-    while (p < hlen && text[p] != '(')
+    int64_t rows = 0, cols = 0;
+    if (!number(&rows))
+        return text.substr(p, 1) == ")" ? FX_IO_ESHAPE : FX_IO_EFORMAT;   // "()" is a scalar
+    if (lit(",)"))
+        return FX_IO_ESHAPE;                                                // one dimension
+    if (!lit(", ") || !number(&cols))
+        return FX_IO_EFORMAT;
+    if (lit(", "))
+        return FX_IO_ESHAPE;                                                // three and more
+    if (!lit("), }"))
+        return FX_IO_EFORMAT;
+    while (p + 1 < hlen && text[p] == ' ')
         p++;
-    p++;
-    int64_t dims[3] = {0, 0, 0};
-    int nd = 0;
-    while (p < hlen && text[p] != ')') {
-        if (text[p] >= '0' && text[p] <= '9') {
-            if (nd >= 3)
-                return FX_IO_ESHAPE;
-            int64_t v = 0;
-            while (p < hlen && text[p] >= '0' && text[p] <= '9')
-                v = v * 10 + (text[p++] - '0');
-            dims[nd++] = v;
-        } else {
-            p++;
-        }
-    }
-    if (nd != 2)
-        return FX_IO_ESHAPE;
-    h->rows = dims[0];
-    h->cols = dims[1];
+    if (p + 1 != hlen || text[p] != '\n')
+        return FX_IO_EFORMAT;
+    h->rows = rows;
+    h->cols = cols;
     h->data_offset = (int64_t)(off + hlen);
     return FX_IO_OK;
 }
@@ -136,6 +143,13 @@ int read_one_points(const char *path, int64_t want_rows, float *out, int64_t *ro
             st = FX_IO_ESHAPE;
         else if (h.rows != want_rows)
             st = FX_IO_EROWS;
+    }
+    if (st == FX_IO_OK) {
+        // the header's shape against the file's size, before anything is sized by it
+        struct stat sb;
+        const unsigned __int128 need = (unsigned __int128)(uint64_t)h.rows * (uint64_t)h.cols * (uint64_t)h.itemsize;
+        if (fstat(fd, &sb) != 0 || need > (unsigned __int128)(sb.st_size > h.data_offset ? sb.st_size - h.data_offset : 0))
+            st = FX_IO_EREAD;
     }
     if (st == FX_IO_OK) {
         if (h.itemsize == 4 && h.cols == 3) {

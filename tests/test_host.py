@@ -536,3 +536,64 @@ def test_records_to_frame_columnar_equals_row_by_row():
     holed = recs[:3] + [{"id": "bad", "raw_path": "", "n_points": None, "proj_hist": None}]
     pd.testing.assert_frame_equal(pca.records_to_frame(holed, 8), row_by_row(holed, 8))
     pd.testing.assert_frame_equal(pca.records_to_frame([], 8), row_by_row([], 8))
+
+
+def test_native_npy_reader_on_random_and_damaged_files(tmp_path):
+    """fx_read_npy_points_f32 on files of random dtype, byte order, memory order, shape and header version, and on
+    files cut short or with bytes of the header overwritten: status 0 means the block holds exactly
+    np.load(path)[:, :3] as float32 (and those values are what the file holds); any other status leaves the file to
+    np.load.  The reader must not take a damaged header for something else."""
+    from numpy.lib import format as npf
+    ing = pkg("ingest")
+    rng = np.random.default_rng(20261112)
+    rows = 37
+    paths, plain = [], []
+    for k in range(400):
+        p = tmp_path / f"r{k:03d}.npy"
+        n = rows if rng.integers(0, 4) else int(rng.integers(0, 80))
+        cols = int(rng.choice([3, 3, 3, 4, 6, 2, 1]))
+        dt = str(rng.choice(["<f4", "<f4", "<f8", ">f4", ">f8", "<f2", "<i4", "<u1", "<c8"]))
+        a = (rng.normal(size=(n, cols)) * 10).astype(np.float32).astype(dt)
+        if rng.integers(0, 5) == 0:
+            a = np.asfortranarray(a)
+        if rng.integers(0, 8) == 0:
+            a = a.reshape(-1)                       # one-dimensional
+        version = (1, 0) if rng.integers(0, 3) else ((2, 0) if rng.integers(0, 2) else (3, 0))
+        with open(p, "wb") as fh:
+            npf.write_array(fh, a, version=version, allow_pickle=False)
+        data = bytearray(p.read_bytes())
+        kind = int(rng.integers(0, 10))
+        if kind == 0 and len(data) > 12:            # cut short
+            data = data[: int(rng.integers(1, len(data)))]
+        elif kind == 1:                             # a byte of the header overwritten
+            data[int(rng.integers(0, min(len(data), 100)))] = int(rng.integers(0, 256))
+        elif kind == 2:                             # bytes appended
+            data += bytes(int(rng.integers(1, 50)))
+        p.write_bytes(bytes(data))
+        paths.append(str(p))
+        # what the native reader is there for: two-dimensional little-endian float files in C order, intact
+        # (bytes behind the data do not matter to np.load either)
+        plain.append(kind >= 2 and a.ndim == 2 and n == rows and cols >= 3 and dt in ("<f4", "<f8") and a.flags.c_contiguous)
+    # a header that promises far more columns than the file holds: a status, no attempt to make room for them
+    liar = tmp_path / "liar.npy"
+    head = b"{'descr': '<f8', 'fortran_order': False, 'shape': (37, 999999999999999), }"
+    head += b" " * (118 - len(head) - 1) + b"\n"
+    liar.write_bytes(b"\x93NUMPY\x01\x00" + len(head).to_bytes(2, "little") + head + bytes(64))
+    paths.append(str(liar))
+    plain.append(False)
+    out = np.full((len(paths), rows, 3), np.nan, dtype=np.float32)
+    status, found = ing.read_points_batch(paths, rows, out, 4)
+    assert status[-1] != 0
+    taken = 0
+    for i, p in enumerate(paths):
+        if status[i] != 0:
+            continue
+        taken += 1
+        ref = np.load(p, allow_pickle=False)        # (a file the native reader takes is one np.load takes)
+        assert ref.ndim == 2 and ref.shape[0] == rows and ref.shape[1] >= 3 and ref.dtype.kind == "f", (p, ref.shape, ref.dtype)
+        want = ref[:, :3].astype(np.float32)
+        np.testing.assert_array_equal(out[i], want, err_msg=p)
+        np.testing.assert_array_equal(want.astype(np.float64), ref[:, :3].astype(np.float64), err_msg=p)   # nothing rounded away
+        assert found[i] == rows
+    assert all(status[i] == 0 for i in range(len(paths)) if plain[i]) and sum(plain) > 20
+    assert taken <= sum(plain) + 12                 # (a damaged byte that leaves the header as it was, or hits the data)
