@@ -597,3 +597,35 @@ def test_native_npy_reader_on_random_and_damaged_files(tmp_path):
         assert found[i] == rows
     assert all(status[i] == 0 for i in range(len(paths)) if plain[i]) and sum(plain) > 20
     assert taken <= sum(plain) + 12                 # (a damaged byte that leaves the header as it was, or hits the data)
+
+
+def test_native_png_decoder_on_random_and_damaged_files(tmp_path):
+    """fx_decode_png_gray_u8 (host threads) on tools/pngfuzz.py's files: status 0 means PIL's bytes; a damaged stream
+    gets a status (or, where the flipped byte changed nothing PIL checks either, PIL's bytes); intact files are all
+    decoded."""
+    import sys
+    from PIL import Image
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tools"))
+    import pngfuzz
+    ing = pkg("ingest")
+    rng = np.random.default_rng(20261112)
+    for batch in range(25):
+        H = int(rng.choice([1, 2, int(rng.integers(3, 64)), int(rng.integers(64, 301)), 224]))
+        W = int(rng.choice([1, 2, int(rng.integers(3, 64)), int(rng.integers(64, 1001)), 224]))
+        n = int(rng.integers(1, 13))
+        paths, damaged = [], []
+        for k in range(n):
+            p = tmp_path / f"b{batch}_{k}.png"
+            pngfuzz.write_png(p, rng, H, W)
+            bad = bool(rng.integers(0, 4) == 0)
+            if bad:
+                pngfuzz.damage(p, rng)
+            paths.append(p)
+            damaged.append(bad)
+        out = np.zeros((n, H, W), dtype=np.uint8)
+        status, _ = ing.decode_png_batch([str(p) for p in paths], H, W, out, 4)
+        for i, p in enumerate(paths):
+            if status[i] == 0:
+                np.testing.assert_array_equal(out[i], np.asarray(Image.open(p).convert("L")), err_msg=f"{p.name} {H}x{W}")
+            else:
+                assert damaged[i], f"{p.name} {H}x{W}: intact file declined with status {int(status[i])}"
