@@ -333,7 +333,8 @@ def test_preprocess_image_signature(gpu, oracle, hu_panels):
 
 
 @pytest.mark.parametrize("h,w,res,crop", [(224, 224, 224, True), (200, 152, 160, True), (97, 130, 100, False),
-                                          (512, 512, 224, True), (64, 64, 512, True), (224, 224, 37, True)])
+                                          (512, 512, 224, True), (64, 64, 512, True), (224, 224, 37, True),
+                                          (512, 512, 512, False), (300, 500, 512, True)])
 def test_moments_summed_on_chip_equal_hu_of_the_masks(gpu, backend, h, w, res, crop):
     """The fused call (moments from the bit mask's row runs) gives bit for bit what the two calls give, with and
     without the silhouettes written; empty, full and single-pixel silhouettes included."""
@@ -344,6 +345,9 @@ def test_moments_summed_on_chip_equal_hu_of_the_masks(gpu, backend, h, w, res, c
     imgs[1] = 0
     imgs[2] = 255
     imgs[2, h // 2, w // 2] = 0        # a single dark pixel
+    imgs[3] = 30                       # an object that fills the view up to a thin light frame: the largest sums
+    imgs[3, :3, :] = imgs[3, -3:, :] = 230
+    imgs[3, :, :3] = imgs[3, :, -3:] = 230
     d = torch.from_numpy(imgs).to(gpu)
     two = eng.silhouette_batch(d, res, 0.05, crop, info=True, backend=backend)
     want = eng.hu_batch(two["mask"], moments=True, hu=True)
