@@ -41,6 +41,38 @@ for (B, H, W) in [(300000, 1, 1), (200000, 3, 5), (100000, 16, 16), (70000, 17, 
     imgs = rng.integers(0, 256, (B, H, W), dtype=np.uint8)
     check(imgs, -1, 255, f"B={B} {H}x{W} gray")
     check(imgs, 127, 255, f"B={B} {H}x{W} binary")
+# rows far apart: offsets within an image beyond 32 bits (views of a 5 GB buffer)
+big = torch.zeros((1, 300, 1 << 24), dtype=torch.uint8, device=dev)
+for (H, W, x0) in [(300, 200, 0), (300, 208, 16), (224, 224, 5), (300, 1500, 3)]:
+    imgs = rng.integers(0, 256, (1, H, W), dtype=np.uint8)
+    view = big[:, :H, x0:x0 + W]
+    view.copy_(torch.from_numpy(imgs).to(dev))
+    for thresh, nb in ((-1, None), (127, 8)):
+        if nb and W > 1024:
+            nb = None
+        got = eng.hu_batch(view, thresh=thresh, moments=True, contour_bins=nb)
+        torch.cuda.synchronize()
+        ref = c.hu_batch(imgs, thresh=thresh, exact=True)
+        assert np.array_equal(got["moments24"].cpu().numpy(), ref["moments24"]), f"pitch 2^24, {H}x{W}+{x0} thresh={thresh}"
+        if nb:
+            want = cpu_ref.contour_pca_features(imgs[0], 127, nb)
+            assert np.allclose(got["cpca"].cpu().numpy()[0, :9], want[:9], rtol=1e-6, atol=1e-30), f"pitch 2^24 contour {H}x{W}"
+    print(f"pitch 2^24 {H}x{W}+{x0}: ok", flush=True)
+# the silhouette stage and the gray fit on such views: the results of the same views stored contiguously
+for (H, W, x0) in [(224, 224, 0), (300, 130, 7)]:
+    yy, xx = np.mgrid[0:H, 0:W]
+    scene = np.clip(235.0 - 195.0 * (((yy - H / 2) / (H / 3)) ** 2 + ((xx - W / 2) / (W / 4)) ** 2 < 1) + rng.normal(0, 8, (H, W)), 0, 255).astype(np.uint8)[None]
+    view = big[:, :H, x0:x0 + W]
+    view.copy_(torch.from_numpy(scene).to(dev))
+    flat = torch.from_numpy(scene).to(dev)
+    for backend in ("opencv", "pil"):
+        a = eng.silhouette_hu_batch(view, 224, 0.05, True, mask=True, info=True, backend=backend)
+        b = eng.silhouette_hu_batch(flat, 224, 0.05, True, mask=True, info=True, backend=backend)
+        torch.cuda.synchronize()
+        assert all(torch.equal(a[k], b[k]) for k in ("mask", "info", "hulog7")), f"silhouette {backend} pitch 2^24 {H}x{W}"
+        assert torch.equal(eng.gray_fit_batch(view, a["info"], 224, 255), eng.gray_fit_batch(flat, b["info"], 224, 255)), f"gray fit pitch 2^24 {H}x{W}"
+    print(f"silhouette / gray fit pitch 2^24 {H}x{W}+{x0}: ok", flush=True)
+del big
 for (H, W) in [(16385, 8), (8, 16385), (0, 8)]:
     try:
         eng.hu_batch(torch.zeros((1, H, W), dtype=torch.uint8, device=dev))
