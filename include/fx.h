@@ -333,9 +333,11 @@ int fx_allgather_features(const void *d_local, int64_t local_rows, int row_float
  * out[i] (n x rows x 3, host memory, e.g. page-locked).  A float64 file is
  * taken over only when float32 holds all its samples exactly (load_sample
  * widens to float64 and the reference computes on those values), otherwise it
- * gets FX_IO_EWIDE and goes through fx_pca_batch_f64.  A file that does not
- * fit gets a status and is left for the caller (np.load handles every other
- * dtype and raises the reference's errors); status[i] / rows_found[i] per file.
+ * gets FX_IO_EWIDE and goes through fx_pca_batch_f64.  Only the header that
+ * numpy.save writes is taken, character for character, and only when the file
+ * holds the bytes its shape promises; a file that does not fit gets a status
+ * and is left for the caller (np.load handles every other header, dtype and
+ * layout and raises the reference's errors); status[i] / rows_found[i] per file.
  */
 int fx_read_npy_points_f32(const char *const *paths, int64_t n, int64_t rows,
                            float *out, int32_t *status, int64_t *rows_found,
