@@ -2513,6 +2513,24 @@ int launch_ragged_on_device(const PcaArgs &A, int64_t B, int64_t total, bool all
     return run_clouds<T>(A, L, Wk, s);
 }
 
+// A CSR batch without a single point (every set empty, so the caller may have no buffer to point at): NaN rows,
+// like every set of fewer than three points.  Anything else without a points pointer is an error.
+int pca_batch_without_points(const char *who, const int64_t *d_offsets, int64_t B, int n_bins, float *d_out, double *d_eig,
+                             hipStream_t s)
+{
+    FX_REQUIRE(d_offsets != nullptr && d_out != nullptr, "%s: NULL argument", who);
+    FX_REQUIRE(n_bins >= 1 && n_bins <= HIST_MAX, "%s: n_bins %d outside 1..%d", who, n_bins, HIST_MAX);
+    int64_t ends[2] = {0, 0};
+    FX_HIP_CHECK(hipMemcpyAsync(&ends[0], d_offsets, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    FX_HIP_CHECK(hipMemcpyAsync(&ends[1], d_offsets + B, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    FX_HIP_CHECK(hipStreamSynchronize(s));
+    FX_REQUIRE(ends[0] == ends[1], "%s: NULL argument (the offsets speak of %lld points)", who, (long long)(ends[1] - ends[0]));
+    FX_HIP_CHECK(hipMemsetAsync(d_out, 0xFF, (size_t)B * (size_t)(9 + n_bins) * sizeof(float), s));   // all bits set: a NaN
+    if (d_eig)
+        FX_HIP_CHECK(hipMemsetAsync(d_eig, 0xFF, (size_t)B * 6 * sizeof(double), s));
+    return FX_OK;
+}
+
 }  // namespace
 
 extern "C" int fx_pca_batch_f32(const float *d_pts, const int64_t *d_offsets, int64_t B, int64_t N, int dims,
@@ -2521,6 +2539,8 @@ extern "C" int fx_pca_batch_f32(const float *d_pts, const int64_t *d_offsets, in
     FX_REQUIRE(B >= 0, "fx_pca_batch_f32: B = %lld", (long long)B);
     if (B == 0)
         return FX_OK;
+    if (!d_pts && d_offsets)
+        return pca_batch_without_points("fx_pca_batch_f32", d_offsets, B, n_bins, d_out, d_eig, (hipStream_t)stream);
     FX_REQUIRE(d_pts && d_out, "fx_pca_batch_f32: NULL argument");
     FX_REQUIRE(dims == 2 || dims == 3, "fx_pca_batch_f32: dims %d must be 2 or 3", dims);
     FX_REQUIRE(n_bins >= 1 && n_bins <= HIST_MAX, "fx_pca_batch_f32: n_bins %d outside 1..%d", n_bins, HIST_MAX);
@@ -2697,6 +2717,8 @@ extern "C" int fx_pca_batch_f64(const double *d_pts, const int64_t *d_offsets, i
     FX_REQUIRE(B >= 0, "fx_pca_batch_f64: B = %lld", (long long)B);
     if (B == 0)
         return FX_OK;
+    if (!d_pts && d_offsets)
+        return pca_batch_without_points("fx_pca_batch_f64", d_offsets, B, n_bins, d_out, d_eig, (hipStream_t)stream);
     FX_REQUIRE(d_pts && d_out, "fx_pca_batch_f64: NULL argument");
     FX_REQUIRE(dims == 2 || dims == 3, "fx_pca_batch_f64: dims %d must be 2 or 3", dims);
     FX_REQUIRE(n_bins >= 1 && n_bins <= HIST_MAX, "fx_pca_batch_f64: n_bins %d outside 1..%d", n_bins, HIST_MAX);

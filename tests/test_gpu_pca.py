@@ -434,3 +434,18 @@ def test_random_batch_geometry_against_oracle(gpu):
     rng = np.random.default_rng(20261112)
     for _ in range(80):
         pcafuzz.run_case(rng, gpu)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_csr_batch_without_a_single_point(gpu, dtype):
+    """Every set empty: the caller has no coordinates to point at.  NaN rows, as for any set of fewer than three
+    points; offsets that speak of points while the pointer is null are refused."""
+    import torch
+    eng, lib = pkg("engine"), pkg("_lib")
+    pts = torch.zeros((0, 3), dtype=torch.float64 if dtype == np.float64 else torch.float32, device=gpu)
+    off = torch.zeros(6, dtype=torch.int64, device=gpu)
+    res = eng.pca_batch(pts, off, 8, False, eig=True)
+    torch.cuda.synchronize()
+    assert tuple(res["out"].shape) == (5, 17) and bool(torch.isnan(res["out"]).all()) and bool(torch.isnan(res["eig"]).all())
+    with pytest.raises(lib.FxError, match="NULL argument"):
+        eng.pca_batch(pts, torch.tensor([0, 4, 9], dtype=torch.int64, device=gpu), 8, False)
