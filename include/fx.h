@@ -139,7 +139,8 @@ int fx_hu_groupstat(const float *d_hulog7, const int64_t *d_group_offsets,
  * src/features/extract_3d_pca_features.py:59-145; the float32 file contents
  * are widened to float64 in-kernel as load_sample does at :48-56).
  *
- *   d_pts       points, `dims` floats each (2 or 3; z = 0 when dims == 2)
+ *   d_pts       points, `dims` floats each (2 or 3; z = 0 when dims == 2); may be
+ *               NULL for a CSR batch whose sets are all empty (NaN rows)
  *   d_offsets   NULL: B sets of exactly N points, set b at point b*N;
  *               else B+1 point offsets on the device (CSR), and N = the number
  *               of points behind d_pts (any upper bound of d_offsets[B]): the
